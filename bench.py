@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/sec of the TagContinuous rollout hot path on MI355X.
+
+Workload (BASELINE.json configs[2]): TagContinuous, 5 taggers x 100 runners, partial
+observation K = 10, run_configs/tag_continuous.yaml physics, num_envs = 2000 PER GPU.
+One "step" = one rollout tick over all replicas of a rank:
+    sample_actions (2 heads, uniform synthetic policy output resident in HBM)
+    -> HipTagContinuousStep_K10 -> reset_when_done_fused
+replayed from C through the C-ABI (include/wd_hip.h) on the stream torch uses.
+value = total env-steps of all ranks / max-over-ranks wall time of the timed region.
+Replicas shard trivially (weak scaling): no collective in the data path; for N > 1 the
+only RCCL traffic is the barrier + the max-reduction of the timing.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+BENCH_CFG = dict(num_taggers=5, num_runners=100, grid_length=20.0, episode_length=500, max_acceleration=0.1,
+                 min_acceleration=-0.1, max_turn=2.356, min_turn=-2.356, num_acceleration_levels=20,
+                 num_turn_levels=20, skill_level_runner=1.0, skill_level_tagger=1.0, max_speed=1.0, seed=274880,
+                 use_full_observation=False, num_other_agents_observed=10, tagging_distance=0.02,
+                 tag_reward_for_tagger=10.0, tag_penalty_for_runner=-10.0, step_penalty_for_tagger=-0.0,
+                 step_reward_for_runner=0.0, edge_hit_penalty=-0.0, end_of_game_reward_for_runner=1.0,
+                 runner_exits_game_after_tagged=True)
+
+
+def step_algorithmic_bytes(N, K, full_obs):
+    """bytes one TagContinuous env-step must move (4-byte elements):
+    reads 5 state + still_in_game + 2 actions per agent + 12; writes 5 state + still_in_game
+    + edge penalty + reward + F obs + K nearest ids per agent + 12."""
+    F = 7 * (N - 1) + 1 if full_obs else 7 * K + 1
+    k_ids = 0 if full_obs else K
+    return 4 * N * (5 + 1 + 2) + 4 * N * (5 + 1 + 1 + 1 + F + k_ids) + 24
+
+
+def cpu_baseline(cfg, target_seconds=12.0):
+    """The oracle's C restatement (oracle/csrc/wd_oracle.c) timed on this host's cores,
+    on a bounded sample of the same workload.  Reported, never the optimisation target."""
+    from oracle import build as obuild
+    from oracle.tag_continuous_np import TagContinuousOracle
+
+    lib = ctypes.CDLL(obuild.build())
+    cores = os.cpu_count() or 1
+    E = 32 * cores
+    orc = TagContinuousOracle(num_envs=E, **cfg)  # seeded start state (test infrastructure)
+    N, K = orc.N, orc.K
+
+    class Cfg(ctypes.Structure):
+        _fields_ = [("n_envs", ctypes.c_int), ("n_agents", ctypes.c_int), ("episode_length", ctypes.c_int),
+                    ("K", ctypes.c_int), ("use_full_observation", ctypes.c_int), ("runner_exits", ctypes.c_int),
+                    ("grid_length", ctypes.c_float), ("max_speed", ctypes.c_float),
+                    ("edge_hit_penalty", ctypes.c_float), ("margin", ctypes.c_float),
+                    ("tag_reward", ctypes.c_float), ("tag_penalty", ctypes.c_float), ("end_reward", ctypes.c_float),
+                    ("n_acc", ctypes.c_int), ("n_turn", ctypes.c_int)]
+
+    c = Cfg(E, N, orc.T, K, int(orc.use_full_observation), int(orc.runner_exits), float(orc.grid_length),
+            float(orc.max_speed), float(orc.edge_hit_penalty), float(orc.distance_margin_for_reward),
+            float(orc.tag_reward_for_tagger), float(orc.tag_penalty_for_runner),
+            float(orc.end_of_game_reward_for_runner), len(orc.acceleration_actions), len(orc.turn_actions))
+    st = {k: np.ascontiguousarray(getattr(orc, k)) for k in
+          ("loc_x", "loc_y", "speed", "direction", "acceleration", "edge_pen", "sig", "num_runners", "timestep", "done")}
+    obs = np.zeros((E, N, orc.obs_dim), np.float32)
+    rew = np.zeros((E, N), np.float32)
+    rng = np.random.RandomState(0)
+    acts = np.stack([rng.randint(0, c.n_acc, size=(E, N)), rng.randint(0, c.n_turn, size=(E, N))], 2).astype(np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.wdo_tc_step.restype = None
+
+    def tick():
+        lib.wdo_tc_step(ctypes.byref(c), P(st["loc_x"]), P(st["loc_y"]), P(st["speed"]), P(st["direction"]),
+                        P(st["acceleration"]), P(orc.agent_types), P(st["edge_pen"]), P(orc.acceleration_actions),
+                        P(orc.turn_actions), P(orc.skill_levels), P(st["sig"]), P(obs), P(acts), P(rew),
+                        P(orc.step_rewards), P(st["num_runners"]), P(st["done"]), P(st["timestep"]),
+                        ctypes.c_int(cores))
+
+    tick()  # warm-up + calibration
+    t0 = time.perf_counter()
+    tick()
+    per_tick = max(time.perf_counter() - t0, 1e-6)
+    ticks = int(max(3, min(400, target_seconds / per_tick)))
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        tick()
+    dt = time.perf_counter() - t0
+    return {"value": E * ticks / dt, "unit": "env_steps/s", "cores": cores, "kind": "port",
+            "sample": f"{E} replicas x {ticks} ticks of the same TagContinuous 5x100 K=10 step "
+                      f"(C restatement of the reference CPU step, OpenMP over replicas, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--num-envs", type=int, default=2000, help="replicas per GPU")
+    ap.add_argument("--full-obs", action="store_true", help="use_full_observation=True variant (F = 729)")
+    ap.add_argument("--mode", choices=("plan", "graph"), default="plan",
+                    help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the HIP path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from warp_drive_amd.env_wrapper import EnvWrapper
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.managers.function_manager import HIPSampler
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    cfg = dict(BENCH_CFG, use_full_observation=bool(args.full_obs))
+    E = args.num_envs
+    w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip", process_id=local_rank)
+    w.reset_all_envs()
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=cfg["seed"] + rank)  # seed + device id, trainer_base.py:249-252
+    create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                      push_data_batch_placeholders=False)
+    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset)
+    steps, warmup = args.steps, args.warmup
+    if args.mode == "graph":
+        steps = max(10, steps // 10 * 10)
+        warmup = max(10, warmup // 10 * 10)
+
+    def run(n):
+        engine.run(n) if args.mode == "plan" else engine.run_graph(n, 10)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(warmup)
+    barrier()
+    # sample the dominant kernel's duration with HIP events on the launch stream inside the
+    # timed region (<= 64 evenly spaced ticks, so the events do not perturb the measurement)
+    if args.mode == "plan":
+        engine.plan.enable_timing(engine.step_entry, sample_stride=max(1, steps // 64), max_samples=64)
+    barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms, kern_n = (engine.plan.read_timing() if args.mode == "plan" else (0.0, 0))
+    if args.mode == "graph" or kern_n == 0:
+        # graph replay cannot carry event records: time the same launch back to back instead
+        engine.plan.enable_timing(engine.step_entry, 1, 64)
+        engine.run(64)
+        torch.cuda.synchronize()
+        kern_ms, kern_n = engine.plan.read_timing()
+    engine.plan.enable_timing(-1, 1, 1)
+
+    if rank == 0:
+        N, K = w.n_agents, cfg["num_other_agents_observed"]
+        bytes_per_launch = step_algorithmic_bytes(N, K, cfg["use_full_observation"]) * E
+        kern_s = kern_ms / max(kern_n, 1) * 1e-3
+        achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(engine.step_kernel_name, {})
+                if rec.get("num_envs") == E and rec.get("full_obs") == bool(args.full_obs):
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec, TagContinuous 5 taggers x 100 runners",
+            "value": world * E * steps / elapsed,
+            "unit": "env_steps/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
+                            f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}, "
+                            f"num_envs={E} per GPU; tick = sample_actions x2 heads + step"
+                            f"{'' if args.no_reset else ' + fused reset'}",
+                "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode,
+                "kernels_per_tick": len(engine.entry_names), "parallelism": f"env-replica sharding x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_us": kern_s * 1e6,
+                "samples": kern_n,
+            },
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as err:  # the baseline is reported context, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "env_steps/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {err}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""numpy oracle for the core service kernels (test infrastructure).
+
+Restates reference warp_drive/cuda_includes/core/random.cu:33-85 (categorical sampler:
+inclusive float32 prefix sum + binary search with kEps), numba_includes/core/random.py:66-105
+(OU process), cuda_includes/core/reset.cu:9-75 (reset when done / undo).
+
+The reference pins its RNG streams only statistically (tests/warp_drive/pycuda_tests/
+test_action_sampler.py:90-156,253-257; numba_tests/test_ou_sampler.py:68-82), so these
+functions take the uniform / normal draws as INPUTS: given the same draws the device must
+return the same indices.  Bitwise RNG parity is unpinned by design.
+"""
+import numpy as np
+
+K_EPS = np.float32(1.0e-8)  # random.cu:9
+
+
+def search_index(cum, p):
+    """Binary search of random.cu:33-49 on one inclusive prefix-sum row."""
+    left, right, r = 0, len(cum) - 1, len(cum) - 1
+    while left <= right:
+        mid = left + (right - left) // 2
+        if abs(np.float32(cum[mid] - p)) < K_EPS:
+            return mid
+        if cum[mid] < p:
+            left = mid + 1
+        else:
+            right = mid - 1
+    return r if left > r else left
+
+
+def sample_actions(distr, u, use_argmax=False):
+    """distr float32 [..., A]; u float32 [...] in (0, 1].  Returns int32 [...]."""
+    distr = np.asarray(distr, dtype=np.float32)
+    A = distr.shape[-1]
+    flat = distr.reshape(-1, A)
+    out = np.empty(flat.shape[0], dtype=np.int32)
+    if use_argmax:  # first strict maximum, random.cu:58-68
+        for r, row in enumerate(flat):
+            best, idx = row[0], 0
+            for i in range(1, A):
+                if best < row[i]:
+                    best, idx = row[i], i
+            out[r] = idx
+        return out.reshape(distr.shape[:-1])
+    uu = np.asarray(u, dtype=np.float32).reshape(-1)
+    for r, row in enumerate(flat):
+        cum = np.empty(A, dtype=np.float32)
+        cum[0] = row[0]
+        for i in range(1, A):
+            cum[i] = np.float32(row[i] + cum[i - 1])  # random.cu:76-81
+        out[r] = search_index(cum, uu[r])
+    return out.reshape(distr.shape[:-1])
+
+
+def sample_actions_counting(distr, u):
+    """The closed form the device uses: #{i : cum_i < u}, clamped to A-1.  Equal to
+    search_index except when u ties a prefix sum to within kEps (measure zero)."""
+    distr = np.asarray(distr, dtype=np.float32)
+    cum = np.cumsum(distr, axis=-1, dtype=np.float32)  # sequential float32 adds
+    cnt = (cum < np.asarray(u, dtype=np.float32)[..., None]).sum(axis=-1)
+    return np.minimum(cnt, distr.shape[-1] - 1).astype(np.int32)
+
+
+def ou_step(ou_state, distr, normal, damping=0.15, stddev=0.2, scale=1.0):
+    """numba random.py:66-105 given the N(0,1) draws."""
+    f = np.float32
+    if f(scale) < f(1e-8):
+        return ou_state, np.asarray(distr, dtype=f)
+    ou = (f(1.0) - f(damping)) * np.asarray(ou_state, f) + f(stddev) * np.asarray(normal, f)
+    return ou.astype(f), (np.asarray(distr, f) + f(scale) * ou).astype(f)
+
+
+def reset_when_done(data, ref, done, force_reset=False):
+    """reset.cu:9-63: rows of finished replicas are restored from the reference copy."""
+    mask = np.ones(len(done), dtype=bool) if force_reset else (np.asarray(done) > 0)
+    out = np.array(data, copy=True)
+    out[mask] = np.asarray(ref)[mask]
+    return out
+
+
+def undo_done_flag_and_reset_timestep(done, timestep, force_reset=False):
+    """reset.cu:65-75"""
+    mask = np.ones(len(done), dtype=bool) if force_reset else (np.asarray(done) > 0)
+    d, t = np.array(done, copy=True), np.array(timestep, copy=True)
+    d[mask] = 0
+    t[mask] = 0
+    return d, t

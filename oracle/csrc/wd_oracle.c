@@ -47,8 +47,10 @@ static inline float np_sincosf(float x, int want_cos) {
   const float two_over_pi = 0x1.45f306p-1f;
   const float c1 = -0x1.921fb0p+00f, c2 = -0x1.5110b4p-22f, c3 = -0x1.846988p-48f;
   const float magic = 0x1.800000p+23f;
-  float q = x * two_over_pi;
-  q = q + magic;
+  /* numpy's kernel is built with FP contraction on its FMA dispatch targets, so the
+   * quadrant is round(fma(x, 2/pi, magic)) - magic: the product is NOT rounded before
+   * the magic add.  It matters exactly when x*2/pi rounds to k + 0.5 (e.g. x = 5*pi/4). */
+  float q = fmaf(x, two_over_pi, magic);
   q = q - magic;
   float r = fmaf(q, c1, x);
   r = fmaf(q, c2, r);

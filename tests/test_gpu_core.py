@@ -1,0 +1,345 @@
+"""Sampler, reset, data/function managers and logger on the MI355X.
+
+Restates the reference's own tests for these components (they all need a device):
+  tests/warp_drive/pycuda_tests/test_action_sampler.py:42-257
+  tests/warp_drive/numba_tests/test_ou_sampler.py:41-82
+  tests/warp_drive/pycuda_tests/test_env_reset.py:38-245
+  tests/warp_drive/numba_tests/test_pool_reset.py:38-141
+  tests/warp_drive/pycuda_tests/test_function_manager.py:71-230
+  tests/warp_drive/pycuda_tests/test_data_manager.py:24-88
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ACT = "sampled_actions"
+
+
+def _managers(num_agents=5, num_envs=2, episode_length=1):
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.data_manager import HIPDataManager
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+
+    require_gpu()
+    dm = HIPDataManager(num_agents=num_agents, episode_length=episode_length, num_envs=num_envs)
+    fm = HIPFunctionManager(num_agents=int(dm.meta_info("n_agents")), num_envs=int(dm.meta_info("n_envs")))
+    fm.load_hip_from_binary_file()
+    return dm, fm
+
+
+def _feed(**kw):
+    from warp_drive_amd.utils.data_feed import DataFeed
+
+    f = DataFeed()
+    for k, v in kw.items():
+        f.add_data(name=k, data=v)
+    return f
+
+
+# ------------------------------------------------------------------------------ sampler
+def test_action_sampler_statistics():
+    from warp_drive_amd.managers.function_manager import HIPSampler
+
+    dm, fm = _managers()
+    sampler = HIPSampler(fm)
+    sampler.init_random(seed=None)
+    dm.push_data_to_device(_feed(**{f"{ACT}_a": np.zeros((2, 5, 1), dtype=np.int32)}), torch_accessible=True)
+    sampler.register_actions(dm, f"{ACT}_a", 3)
+    assert dm.get_shape(f"{ACT}_a_cum_distr") == (2, 5, 3)
+    p = np.array([[[0.333, 0.333, 0.333], [0.2, 0.5, 0.3], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]],
+                  [[0.1, 0.7, 0.2], [0.7, 0.2, 0.1], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]]])
+    dist = torch.from_numpy(p).float().cuda()
+    n = 10000
+    out = torch.empty((n, 2, 5), dtype=torch.int32, device="cuda")
+    for i in range(n):
+        sampler.sample(dm, dist, action_name=f"{ACT}_a")
+        out[i] = dm.data_on_device_via_torch(f"{ACT}_a")[:, :, 0]
+    a = out.cpu().numpy()
+    for e in range(2):
+        for g in range(5):
+            for k in range(3):
+                freq = (a[:, e, g] == k).mean()
+                if p[e, g, k] in (0.0, 1.0):
+                    assert freq == p[e, g, k]  # one-hot exact, zero-probability never drawn
+                else:
+                    assert abs(freq - p[e, g, k]) <= 0.1 * p[e, g, k] + 1e-9
+    # independence across threads / replicas / iterations (test_action_sampler.py:159-257)
+    dm.push_data_to_device(_feed(**{f"{ACT}_b": np.zeros((2, 5, 1), dtype=np.int32)}), torch_accessible=True)
+    sampler.register_actions(dm, f"{ACT}_b", 4)
+    dist = torch.full((2, 5, 4), 0.25, device="cuda")
+    out = torch.empty((n, 2, 5), dtype=torch.int32, device="cuda")
+    for i in range(n):
+        sampler.sample(dm, dist, action_name=f"{ACT}_b")
+        out[i] = dm.data_on_device_via_torch(f"{ACT}_b")[:, :, 0]
+    b = out.cpu().numpy().astype(np.float64)
+    assert b.reshape(n, -1).std(axis=1).mean() > 0.9  # threads of one draw differ
+    assert b.std(axis=0).mean() > 0.9                # successive draws differ
+    assert abs(b.mean() - 1.5) < 0.02
+    assert abs(np.corrcoef(b[:-1].reshape(-1), b[1:].reshape(-1))[0, 1]) < 0.02
+
+
+def test_sampler_given_draws_matches_reference_search():
+    """same uniforms -> same indices as the reference's prefix-sum + binary search"""
+    from oracle.core_np import sample_actions, sample_actions_counting
+
+    rng = np.random.RandomState(0)
+    p = rng.dirichlet(np.ones(21), size=4000).astype(np.float32)
+    u = ((rng.randint(0, 1 << 24, size=4000) + 1) * 2.0 ** -24).astype(np.float32)
+    np.testing.assert_array_equal(sample_actions(p, u), sample_actions_counting(p, u))
+
+
+def test_sampler_argmax_and_large_shapes():
+    from warp_drive_amd.managers.function_manager import HIPSampler
+
+    E, N, A = 300, 105, 21
+    dm, fm = _managers(num_agents=N, num_envs=E)
+    sampler = HIPSampler(fm)
+    sampler.init_random(seed=7)
+    dm.push_data_to_device(_feed(**{ACT: np.zeros((E, N, 1), dtype=np.int32)}), torch_accessible=True)
+    sampler.register_actions(dm, ACT, A)
+    rng = np.random.RandomState(1)
+    p = rng.dirichlet(np.ones(A), size=(E, N)).astype(np.float32)
+    dist = torch.from_numpy(p).cuda()
+    sampler.sample(dm, dist, ACT, use_argmax=True)
+    np.testing.assert_array_equal(dm.pull_data_from_device(ACT)[..., 0], p.argmax(-1))
+    counts = np.zeros(A)
+    reps = 60
+    for _ in range(reps):
+        sampler.sample(dm, dist, ACT)
+        got = dm.pull_data_from_device(ACT)[..., 0]
+        assert got.min() >= 0 and got.max() < A
+        counts += np.bincount(got.reshape(-1), minlength=A)
+    expected = p.reshape(-1, A).sum(0) * reps
+    assert np.abs(counts - expected).max() < 6 * np.sqrt(expected.max())
+    # one-hot rows are exact at scale
+    hot = rng.randint(0, A, size=(E, N))
+    dist = torch.from_numpy(np.eye(A, dtype=np.float32)[hot]).cuda()
+    for _ in range(20):
+        sampler.sample(dm, dist, ACT)
+        np.testing.assert_array_equal(dm.pull_data_from_device(ACT)[..., 0], hot)
+
+
+def test_ou_sampler_statistics():
+    """stationary std = sigma / sqrt(1 - (1 - theta)^2) and the lag-k covariance of the OU
+    process (numba_tests/test_ou_sampler.py:68-82)"""
+    from warp_drive_amd.managers.function_manager import HIPSampler
+
+    E, N = 1000, 5
+    dm, fm = _managers(num_agents=N, num_envs=E)
+    sampler = HIPSampler(fm)
+    sampler.init_random(seed=3)
+    dm.push_data_to_device(_feed(**{ACT: np.zeros((E, N, 1), dtype=np.float32)}), torch_accessible=True)
+    sampler.register_actions(dm, ACT, 1, is_deterministic=True)
+    assert dm.get_shape(f"{ACT}_ou_state") == (E, N, 1)
+    mu = torch.zeros((E, N, 1), device="cuda")
+    damping, stddev, steps = 0.15, 0.2, 4000
+    out = torch.empty((steps, E, N), device="cuda")
+    for i in range(steps):
+        sampler.sample(dm, mu, ACT, damping=damping, stddev=stddev, scale=1.0)
+        out[i] = dm.data_on_device_via_torch(ACT)[:, :, 0]
+    x = out[500:].cpu().numpy().astype(np.float64)
+    std = stddev / np.sqrt(1 - (1 - damping) ** 2)
+    assert abs(x.std() - std) < 2e-3
+    lag = 10
+    cov = (x[:-lag] * x[lag:]).mean()
+    assert abs(cov - std ** 2 * (1 - damping) ** lag) < 2e-3
+    assert abs(x.mean()) < 2e-3
+    # scale ~ 0 passes the deterministic action through
+    mu = torch.rand((E, N, 1), device="cuda")
+    sampler.sample(dm, mu, ACT, scale=0.0)
+    np.testing.assert_array_equal(dm.pull_data_from_device(ACT), mu.cpu().numpy())
+
+
+# -------------------------------------------------------------------------------- reset
+@pytest.mark.parametrize("torch_accessible", [False, True])
+def test_reset_when_done(torch_accessible):
+    from warp_drive_amd.managers.function_manager import HIPEnvironmentReset
+    from warp_drive_amd.utils.data_feed import DataFeed
+
+    dm, fm = _managers()
+    resetter = HIPEnvironmentReset(fm)
+    f = DataFeed()
+    init = {
+        "f1": np.array([1.5, -2.5], dtype=np.float32),                               # 1-D float
+        "i1": np.array([7, 9], dtype=np.int32),                                      # 1-D int
+        "f2": np.arange(10, dtype=np.float32).reshape(2, 5) / 10,                    # 2-D float
+        "i2": np.arange(10, dtype=np.int32).reshape(2, 5),                           # 2-D int
+        "f3": np.arange(30, dtype=np.float32).reshape(2, 5, 3) / 7,                  # 3-D float
+        "i3": np.arange(60, dtype=np.int32).reshape(2, 5, 2, 3),                     # 4-D int
+    }
+    for k, v in init.items():
+        f.add_data(name=k, data=v, save_copy_and_apply_at_reset=True)
+    dm.push_data_to_device(f, torch_accessible=torch_accessible)
+    assert dm.reset_data_list == list(init)
+
+    def scramble():
+        for k, v in init.items():
+            dm._host_data[k] = (v * 0 - 3).astype(v.dtype)
+            dm.reset_device(k)
+            dm._host_data[k] = v
+
+    def set_done(vals):
+        dm.data_on_device_via_torch("_done_")[:] = torch.tensor(vals, dtype=torch.int32)
+
+    scramble()
+    set_done([1, 0])
+    resetter.reset_when_done(dm, mode="if_done")
+    for k, v in init.items():
+        got = dm.pull_data_from_device(k)
+        np.testing.assert_array_equal(got[0], v[0], err_msg=k)      # env 0 restored
+        np.testing.assert_array_equal(got[1], v[1] * 0 - 3, err_msg=k)  # env 1 untouched
+    np.testing.assert_array_equal(dm.pull_data_from_device("_done_"), [0, 0])
+    np.testing.assert_array_equal(dm.pull_data_from_device("_timestep_"), [0, 0])
+    scramble()
+    set_done([0, 0])
+    resetter.reset_when_done(dm, mode="force_reset")
+    for k, v in init.items():
+        np.testing.assert_array_equal(dm.pull_data_from_device(k), v, err_msg=k)
+    # undo_done_after_reset=False keeps the flags
+    set_done([0, 1])
+    resetter.reset_when_done(dm, mode="if_done", undo_done_after_reset=False)
+    np.testing.assert_array_equal(dm.pull_data_from_device("_done_"), [0, 1])
+
+
+def test_reset_from_pool():
+    from warp_drive_amd.managers.function_manager import HIPEnvironmentReset
+    from warp_drive_amd.utils.data_feed import DataFeed
+
+    E = 4000
+    dm, fm = _managers(num_agents=3, num_envs=E)
+    resetter = HIPEnvironmentReset(fm)
+    f = DataFeed()
+    f.add_data(name="a", data=np.zeros((E, 3), dtype=np.float32))
+    f.add_data(name="b", data=np.zeros((E, 3, 2), dtype=np.int32))
+    pool_a = np.arange(5 * 3, dtype=np.float32).reshape(5, 3)
+    pool_b = np.arange(5 * 6, dtype=np.int32).reshape(5, 3, 2) * 10
+    f.add_pool_for_reset(name="a_reset_pool", data=pool_a, reset_target="a")
+    f.add_pool_for_reset(name="b_reset_pool", data=pool_b, reset_target="b")
+    dm.push_data_to_device(f)
+    assert dm.reset_target_to_pool == {"a": "a_reset_pool", "b": "b_reset_pool"}
+    resetter.init_reset_pool(dm, seed=5)
+    dm.data_on_device_via_torch("_done_")[:] = 1
+    resetter.reset_when_done(dm, mode="if_done")
+    a, b = dm.pull_data_from_device("a"), dm.pull_data_from_device("b")
+    row_a = (a[:, 0] / 3).astype(int)
+    row_b = b[:, 0, 0] // 60
+    np.testing.assert_array_equal(a, pool_a[row_a])
+    np.testing.assert_array_equal(b, pool_b[row_b])
+    np.testing.assert_array_equal(row_a, row_b)  # one draw per replica per reset call
+    counts = np.bincount(row_a, minlength=5) / E
+    assert np.abs(counts - 0.2).max() < 0.03      # uniform over the pool (test_pool_reset.py:118-141)
+    np.testing.assert_array_equal(dm.pull_data_from_device("_done_"), 0)
+    a0 = a.copy()
+    dm.data_on_device_via_torch("_done_")[:] = 1
+    resetter.reset_when_done(dm, mode="if_done")
+    assert (dm.pull_data_from_device("a") != a0).any(axis=1).mean() > 0.6  # a fresh draw
+
+
+# --------------------------------------------------------------- data / function manager
+def test_data_manager_roundtrip_and_casting():
+    dm, _ = _managers()
+    from warp_drive_amd.utils.data_feed import DataFeed
+
+    f = DataFeed()
+    f.add_data(name="X", data=np.array([[1, 2, 3, 4, 5], [0, 0, 0, 0, 0]]))          # int64 -> int32
+    f.add_data(name="Y", data=[[0.1, 0.2, 0.3, 0.4, 0.5], [0.0, 0.0, 0.0, 0.0, 0.0]])  # float64 -> float32
+    f.add_data(name="a", data=100)
+    f.add_data(name="b", data=0.5)
+    f.add_data(name="flag", data=True)
+    dm.push_data_to_device(f)
+    assert dm.get_dtype("X") == "int32" and dm.get_dtype("Y") == "float32"
+    assert dm.device_data("a") == 100 and dm.device_data("a").dtype == np.int32
+    assert dm.device_data("b").dtype == np.float32 and dm.device_data("flag").dtype == np.int32
+    np.testing.assert_array_equal(dm.pull_data_from_device("X"), [[1, 2, 3, 4, 5], [0, 0, 0, 0, 0]])
+    assert dm.pull_data_from_device("Y").dtype == np.float32
+    assert not dm.is_data_on_device_via_torch("X")
+    f2 = DataFeed()
+    f2.add_data(name="Z", data=np.ones((2, 5), dtype=np.float32))
+    dm.push_data_to_device(f2, torch_accessible=True)
+    assert dm.is_data_on_device_via_torch("Z")
+    z = dm.data_on_device_via_torch("Z")
+    z += 1  # torch writes in place; the manager sees the same memory
+    np.testing.assert_array_equal(dm.pull_data_from_device("Z"), 2)
+    assert int(dm.device_data("Z")) == z.data_ptr()
+    with pytest.raises(AssertionError):
+        dm.push_data_to_device(f2)  # duplicate registration
+
+
+def test_function_manager_testkernel_and_log():
+    """test_function_manager.py:71-230: the dummy `testkernel`, the episode logger and a
+    per-replica reset driven by the done flag it sets."""
+    from warp_drive_amd.managers.function_manager import HIPEnvironmentReset, HIPLogController
+    from warp_drive_amd.utils.data_feed import DataFeed
+
+    T = 5
+    dm, fm = _managers(episode_length=T)
+    fm.initialize_functions(["testkernel"])
+    kernel = fm.get_function("testkernel")
+    f = DataFeed()
+    f.add_data(name="X", data=np.array([[0.1, 0.2, 0.3, 0.4, 0.5], [0.6, 0.7, 0.8, 0.9, 1.0]]),
+               save_copy_and_apply_at_reset=True, log_data_across_episode=True)
+    f.add_data(name="Y", data=np.array([[1, 2, 3, 4, 5], [0, 0, 0, 0, 0]]),
+               save_copy_and_apply_at_reset=True, log_data_across_episode=True)
+    f.add_data(name="multiplier", data=2.0)
+    f.add_data(name="target", data=40)
+    dm.push_data_to_device(f)
+    t = DataFeed()
+    t.add_data(name="actions", data=np.zeros((2, 5, 3), dtype=np.int32))
+    dm.push_data_to_device(t, torch_accessible=True)
+    logger, resetter = HIPLogController(fm), HIPEnvironmentReset(fm)
+    logger.reset_log(dm, env_id=0)
+    x0, y0 = dm.pull_data_from_device("X").copy(), dm.pull_data_from_device("Y").copy()
+    for step in range(1, 4):
+        # both calling conventions of the reference's env classes
+        args = (dm.device_data("X"), dm.device_data("Y"), dm.device_data("_done_"), dm.device_data("actions"),
+                dm.device_data("multiplier"), dm.device_data("target"), np.int32(step), dm.meta_info("episode_length"),
+                dm.meta_info("n_agents"), dm.meta_info("n_envs"))
+        if step % 2:
+            kernel(*args, block=fm.block, grid=fm.grid)
+        else:
+            kernel[fm.grid, fm.block](*args)
+        logger.update_log(dm, step)
+    np.testing.assert_allclose(dm.pull_data_from_device("X"), x0 / 8, rtol=1e-6)
+    np.testing.assert_array_equal(dm.pull_data_from_device("Y"), y0 * 8)
+    np.testing.assert_array_equal(dm.pull_data_from_device("actions"), np.tile([0, 1, 2], (2, 5, 1)))
+    np.testing.assert_array_equal(dm.pull_data_from_device("_done_"), [1, 0])  # env 0 reached y >= 40
+    log = logger.fetch_log(dm)
+    assert log["X_for_log"].shape == (4, 5)
+    np.testing.assert_allclose(log["X_for_log"][:, 0], x0[0, 0] / 2.0 ** np.arange(4), rtol=1e-6)
+    np.testing.assert_array_equal(log["Y_for_log"][3], y0[0] * 8)
+    resetter.reset_when_done(dm)
+    np.testing.assert_array_equal(dm.pull_data_from_device("X")[0], x0[0])
+    np.testing.assert_allclose(dm.pull_data_from_device("X")[1], x0[1] / 8, rtol=1e-6)
+    with pytest.raises(AssertionError):
+        fm.get_function("no_such_kernel")
+    with pytest.raises(Exception):
+        fm.initialize_functions(["no_such_kernel"])
+
+
+def test_cartpole_vs_oracle():
+    """BASELINE config[5] kernel against the numpy restatement of cartpole_step_numba.py
+    (parity unpinned: the reference's CPU step is third-party gym)."""
+    from oracle.cartpole_np import CartPoleOracle
+    from tests.hip_harness import OBS, REW, make_wrapper, pull, push_actions, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+
+    require_gpu()
+    E, T = 5000, 60
+    env = CUDAClassicControlCartPoleEnv(episode_length=T, seed=32145)
+    w = make_wrapper(env, E)
+    orc = CartPoleOracle(E, T, initial_state=pull(w, "state")[0, 0])
+    rng = np.random.RandomState(0)
+    for t in range(150):
+        a = rng.randint(0, 2, size=(E, 1, 1)).astype(np.int32)
+        push_actions(w, a)
+        w.step_all_envs()
+        orc.step(a)
+        np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state, err_msg=f"t={t}")
+        np.testing.assert_array_equal(pull(w, OBS)[:, 0], orc.obs)
+        np.testing.assert_array_equal(pull(w, "_done_"), orc.done)
+        np.testing.assert_array_equal(pull(w, REW)[:, 0], orc.rewards)
+        w.reset_only_done_envs()
+        orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)

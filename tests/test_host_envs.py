@@ -1,0 +1,62 @@
+"""Host-side (CPU) environments of the package vs fixtures recorded from the reference.
+Covers BASELINE config[0]: TagGridWorld 6x6, 5 agents, num_envs=2, pure CPU step()."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from warp_drive_amd.env_wrapper import EnvWrapper
+from warp_drive_amd.envs.tag_continuous import TagContinuous
+from warp_drive_amd.envs.tag_gridworld import TagGridWorld
+
+
+def _load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return d, json.loads(str(d["config"]))
+
+
+def _obs(o, n):
+    return np.stack([np.asarray(o[a], dtype=np.float64) for a in range(n)])
+
+
+@pytest.mark.parametrize("tag", ["full", "partial", "g6", "g10"])
+def test_gridworld_cpu_backend(golden_dir, tag):
+    d, cfg = _load(golden_dir, f"gw_traj_{tag}.npz")
+    E = d["actions"].shape[1]
+    envs = [EnvWrapper(env_obj=TagGridWorld(**cfg), env_backend="cpu") for _ in range(E)]
+    n = envs[0].n_agents
+    for i, e in enumerate(envs):
+        np.testing.assert_array_equal(_obs(e.reset(), n), d["obs_at_reset"][i])
+    for t in range(d["actions"].shape[0]):
+        for i, e in enumerate(envs):
+            obs, rew, done, _ = e.step({a: int(d["actions"][t, i, a]) for a in range(n)})
+            np.testing.assert_array_equal(_obs(obs, n), d["obs"][t, i])
+            np.testing.assert_array_equal(np.array([rew[a] for a in range(n)]), d["rewards"][t, i])
+            assert bool(done["__all__"]) == bool(d["done"][t, i])
+            np.testing.assert_array_equal(e.env.global_state["loc_x"][e.env.timestep], d["loc_x"][t, i])
+            if done["__all__"]:
+                e.reset()
+
+
+@pytest.mark.parametrize("tag", ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100"])
+def test_tag_continuous_cpu_backend(golden_dir, tag):
+    d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
+    E = d["actions"].shape[1]
+    envs = [EnvWrapper(env_obj=TagContinuous(**cfg), env_backend="cpu") for _ in range(E)]
+    n = envs[0].n_agents
+    for i, e in enumerate(envs):
+        np.testing.assert_array_equal(_obs(e.reset(), n), d["obs_at_reset"][i])
+    T = min(d["actions"].shape[0], 60)
+    for t in range(T):
+        for i, e in enumerate(envs):
+            obs, rew, done, _ = e.step({a: d["actions"][t, i, a] for a in range(n)})
+            ts = e.env.timestep
+            for k in ("loc_x", "loc_y", "speed", "direction", "acceleration"):
+                np.testing.assert_array_equal(e.env.global_state[k][ts], d[k][t, i], err_msg=f"{k} t={t}")
+            np.testing.assert_array_equal(e.env.still_in_the_game, d["still_in_the_game"][t, i])
+            np.testing.assert_array_equal(np.array([float(rew[a]) for a in range(n)]), d["rewards"][t, i])
+            np.testing.assert_array_equal(_obs(obs, n), d["obs"][t, i], err_msg=f"obs t={t}")
+            assert bool(done["__all__"]) == bool(d["done"][t, i])
+            if done["__all__"]:
+                e.reset()

@@ -102,6 +102,17 @@ def _clib():
     return lib
 
 
+def _tie_neighbourhoods():
+    """+-200 ulps around (k + 0.5) * pi/2 (quadrant rounding ties, e.g. 5*pi/4) and k * pi/2"""
+    out = []
+    for k in range(9):
+        for c in ((k + 0.5) * np.pi / 2, k * np.pi / 2):
+            bits = np.array([c], dtype=f32).view(np.int32)[0] + np.arange(-200, 201)
+            out.append(bits.astype(np.int32).view(f32))
+    x = np.concatenate(out)
+    return x[(x >= 0) & (x <= 7)]
+
+
 def test_c_sincos_bit_identical_to_numpy():
     """np_sincosf() in oracle/csrc/wd_oracle.c (and the identical device routine)
     must reproduce numpy's float32 cos/sin bit for bit on [0, 2pi]."""
@@ -111,6 +122,7 @@ def test_c_sincos_bit_identical_to_numpy():
         (rng.rand(2_000_000) * 2 * np.pi).astype(f32),
         np.array([0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi], dtype=f32),
         np.linspace(0, 2 * np.pi, 100_001).astype(f32),
+        _tie_neighbourhoods(),
     ])
     out = np.empty_like(x)
     lib.wdo_np_cosf(x.ctypes.data, out.ctypes.data, x.size)
@@ -127,3 +139,49 @@ def test_powf2_is_numpy_scalar_power():
     lib.wdo_powf2(x.ctypes.data, out.ctypes.data, x.size)
     ref = np.array([v ** 2 for v in x], dtype=f32)
     np.testing.assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("tag", ["test2", "test3", "tagheavy", "bench5x100", "bench5x100_full"])
+def test_c_step_matches_reference(golden_dir, tag):
+    """The C restatement (bench.py's cpu_baseline 'port') replays the reference bit-exactly."""
+    d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
+    E = d["actions"].shape[1]
+    orc = TagContinuousOracle(num_envs=E, **cfg)  # supplies the seeded start + tables
+    lib = ctypes.CDLL(obuild.build())
+    lib.wdo_tc_step.restype = None
+
+    class Cfg(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int) for n in ("E", "N", "T", "K", "full", "exits")] + \
+                   [(n, ctypes.c_float) for n in ("L", "vmax", "edge", "margin", "tr", "tp", "er")] + \
+                   [("na", ctypes.c_int), ("nt", ctypes.c_int)]
+
+    c = Cfg(E, orc.N, orc.T, orc.K, int(orc.use_full_observation), int(orc.runner_exits),
+            float(orc.grid_length), float(orc.max_speed), float(orc.edge_hit_penalty),
+            float(orc.distance_margin_for_reward), float(orc.tag_reward_for_tagger),
+            float(orc.tag_penalty_for_runner), float(orc.end_of_game_reward_for_runner),
+            len(orc.acceleration_actions), len(orc.turn_actions))
+    st = {k: np.ascontiguousarray(getattr(orc, k)).copy() for k in
+          ("loc_x", "loc_y", "speed", "direction", "acceleration", "edge_pen", "sig", "num_runners",
+           "timestep", "done")}
+    obs = np.zeros((E, orc.N, orc.obs_dim), f32)
+    rew = np.zeros((E, orc.N), f32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for t in range(min(d["actions"].shape[0], 120)):
+        acts = np.ascontiguousarray(d["actions"][t], dtype=np.int32)
+        lib.wdo_tc_step(ctypes.byref(c), P(st["loc_x"]), P(st["loc_y"]), P(st["speed"]), P(st["direction"]),
+                        P(st["acceleration"]), P(orc.agent_types), P(st["edge_pen"]),
+                        P(orc.acceleration_actions), P(orc.turn_actions), P(orc.skill_levels), P(st["sig"]),
+                        P(obs), P(acts), P(rew), P(orc.step_rewards), P(st["num_runners"]), P(st["done"]),
+                        P(st["timestep"]), ctypes.c_int(2))
+        for k, g in (("loc_x", "loc_x"), ("loc_y", "loc_y"), ("speed", "speed"), ("direction", "direction"),
+                     ("acceleration", "acceleration"), ("sig", "still_in_the_game"), ("num_runners", "num_runners")):
+            np.testing.assert_array_equal(st[k], d[g][t], err_msg=f"{k} t={t}")
+        np.testing.assert_array_equal(st["done"].astype(bool), d["done"][t])
+        np.testing.assert_array_equal(rew, d["rewards"][t].astype(f32))
+        np.testing.assert_array_equal(obs, d["obs"][t].astype(f32), err_msg=f"obs t={t}")
+        m = st["done"] > 0  # device-style reset of finished replicas
+        for k, v in (("loc_x", orc.start_x), ("loc_y", orc.start_y), ("direction", orc.start_dir)):
+            st[k][m] = v
+        for k, v in (("speed", 0), ("acceleration", 0), ("edge_pen", 0), ("sig", 1),
+                     ("num_runners", orc.num_runners0), ("timestep", 0), ("done", 0)):
+            st[k][m] = v

@@ -1,0 +1,72 @@
+"""Build the native pieces of warp_drive_amd in-tree.
+
+  csrc/libwdhip.so       C-ABI runtime (include/wd_hip.h), host-only C++; binds
+                         libamdhip64 at run time, so it is NOT linked against it.
+  csrc/wd_kernels.hsaco  gfx950 code object with every kernel of the rollout path,
+                         loaded through wd_module_load().
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container;
+the built files are git-ignored but travel to the GPU box with the tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+KDIR = os.path.join(CSRC, "kernels")
+LIB = os.path.join(CSRC, "libwdhip.so")
+HSACO = os.path.join(CSRC, "wd_kernels.hsaco")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+# -ffp-contract=off + correctly rounded div/sqrt are part of the parity contract
+# (see csrc/kernels/wd_common.h); do not change them without re-running the parity suite.
+KERNEL_FLAGS = [
+    "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _hipcc():
+    return shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+
+
+def build_runtime(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "wd_runtime.cpp"), os.path.join(ROOT, "include", "wd_hip.h")]
+    if not force and _newer(LIB, srcs):
+        return LIB
+    cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-result",
+           "-D__HIP_PLATFORM_AMD__", f"-I{ROCM}/include", f"-I{ROOT}/include", srcs[0],
+           "-o", LIB, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_kernels(force=False, verbose=False, extra_flags=()):
+    srcs = [os.path.join(KDIR, f) for f in sorted(os.listdir(KDIR)) if f.endswith((".hip", ".h"))]
+    if not force and _newer(HSACO, srcs):
+        return HSACO
+    cmd = [_hipcc(), *KERNEL_FLAGS, *extra_flags, os.path.join(KDIR, "wd_kernels.hip"), "-o", HSACO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HSACO
+
+
+def build_all(force=False, verbose=False):
+    return build_runtime(force, verbose), build_kernels(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,96 @@
+// wd_common.h -- device helpers shared by all gfx950 kernels of the rollout path.
+//
+// Numerics contract (see DESIGN.md "Parity"): the whole code object is compiled with
+// -ffp-contract=off, so a*b+c rounds twice exactly like numpy's separate ufuncs; the
+// only fused operations are the explicit __builtin_fmaf calls in wd_np_sincosf(), which
+// restates numpy's float32 cos/sin kernel (the reference CPU step calls np.cos/np.sin on
+// float32 arrays, example_envs/tag_continuous/tag_continuous.py:370-373).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WD_WAVE 64
+
+// ---------------------------------------------------------------------------------
+// numpy float32 sin/cos, bit-exact (Cody-Waite 3-term reduction by pi/2 + minimax
+// polynomials; numpy/_core/src/umath/loops_trigonometric.dispatch.*).  Valid for
+// |x| <= 71476: directions are kept in [0, 2*pi].
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void wd_np_sincosf(float x, float &sin_out, float &cos_out) {
+  const float two_over_pi = 0x1.45f306p-1f;
+  const float c1 = -0x1.921fb0p+00f, c2 = -0x1.5110b4p-22f, c3 = -0x1.846988p-48f;
+  const float magic = 0x1.800000p+23f;
+  // numpy builds this kernel with FP contraction on its FMA dispatch targets: the product
+  // x*2/pi is not rounded before the magic add (matters when it lands on k + 0.5).
+  float q = __builtin_fmaf(x, two_over_pi, magic);
+  q = q - magic;
+  float r = __builtin_fmaf(q, c1, x);
+  r = __builtin_fmaf(q, c2, r);
+  r = __builtin_fmaf(q, c3, r);
+  const float r2 = r * r;
+  float c = __builtin_fmaf(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
+  c = __builtin_fmaf(c, r2, 0x1.55553cp-05f);
+  c = __builtin_fmaf(c, r2, -0x1.000000p-01f);
+  c = __builtin_fmaf(c, r2, 0x1.000000p+00f);
+  float s = __builtin_fmaf(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+  s = __builtin_fmaf(s, r2, 0x1.11119ap-07f);
+  s = __builtin_fmaf(s, r2, -0x1.555556p-03f);
+  s = __builtin_fmaf(s, r2, 0.0f);
+  s = __builtin_fmaf(s, r, r);
+  const int iq = (int)q;
+  // sin: quadrant iq ; cos: quadrant iq + 1
+  float sv = (iq & 1) == 0 ? s : c;
+  if (iq & 2) sv = 0.0f - sv;
+  const int ic = iq + 1;
+  float cv = (ic & 1) == 0 ? s : c;
+  if (ic & 2) cv = 0.0f - cv;
+  sin_out = sv;
+  cos_out = cv;
+}
+
+// numpy remainder (npy_divmodf): result carries the sign of the divisor.
+__device__ __forceinline__ float wd_np_remainderf(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.0f) {
+    if ((b < 0.0f) != (m < 0.0f)) m += b;
+  } else {
+    m = copysignf(0.0f, b);
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11).  Stateless: the draw
+// for (thread, epoch) is a pure function of (seed, thread, epoch, stream tag), so the
+// only RNG state in HBM is one 32-bit epoch counter per thread.
+// ---------------------------------------------------------------------------------
+struct wd_u4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ wd_u4 wd_philox4x32_10(wd_u4 ctr, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    wd_u4 n;
+    n.x = hi1 ^ ctr.y ^ k0;
+    n.y = lo1;
+    n.z = hi0 ^ ctr.w ^ k1;
+    n.w = lo0;
+    ctr = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return ctr;
+}
+
+// uniform in (0, 1], 24 random bits  (curand_uniform's range, random.cu:72)
+__device__ __forceinline__ float wd_u01_open_closed(uint32_t bits) {
+  return (float)((bits >> 8) + 1u) * 0x1.0p-24f;
+}
+
+// RNG state layout in HBM (uint32 words): [0]=seed lo, [1]=seed hi, [2]=n_threads,
+// [3]=reserved, [4 + tid] = per-thread epoch counter.
+#define WD_RNG_HEADER 4

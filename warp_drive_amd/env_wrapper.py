@@ -1,0 +1,164 @@
+"""EnvWrapper: runs an environment on the CPU or on the MI355X.
+
+API mirror of reference warp_drive/env_wrapper.py:28-408.  Differences:
+  * one device backend, `env_backend="hip"` ("pycuda"/"numba"/True are accepted as
+    aliases so reference scripts keep working); it fails loudly when libwdhip.so, the
+    code object or the GPU is missing -- there is no silent CPU fallback;
+  * the code object is prebuilt, so `testing_mode` simply loads it (the reference
+    loads a fixed 2-env x 5-agent test binary, :196-206);
+  * blocks_per_env must be 1 (multi-block replicas are out of scope).
+First reset happens on the host and pushes every array once; all later resets and
+steps run on the device in place (:264-353).
+"""
+import logging
+
+import numpy as np
+
+from warp_drive_amd.managers.function_manager import CUDAFunctionFeed
+from warp_drive_amd.utils.gpu_environment_context import CUDAEnvironmentContext
+from warp_drive_amd.utils.spaces import obs_dict_to_spaces
+
+_HIP_ALIASES = ("hip", "pycuda", "numba")
+
+
+def _normalise_backend(env_backend):
+    if isinstance(env_backend, bool):  # pre-2.0 `use_cuda=True/False`
+        return "hip" if env_backend else "cpu"
+    if env_backend in _HIP_ALIASES:
+        return "hip"
+    if env_backend != "cpu":
+        logging.warning("Environment backend not recognized, defaulting to cpu")
+    return "cpu"
+
+
+class EnvWrapper:
+    def __init__(self, env_obj=None, env_name=None, env_config=None, num_envs=1, blocks_per_env=None,
+                 env_backend="cpu", testing_mode=False, testing_bin_filename=None, env_registrar=None,
+                 event_messenger=None, process_id=0, use_cuda=None):
+        if use_cuda is not None:  # deprecated spelling (reference Argfix, :45)
+            env_backend = use_cuda
+        env_backend = _normalise_backend(env_backend)
+        if env_obj is not None:
+            self.env = env_obj
+        else:
+            assert env_name is not None and env_config is not None and env_registrar is not None
+            self.env = env_registrar.get(env_name, env_backend)(**env_config)
+        self.n_agents = self.env.num_agents
+        self.episode_length = self.env.episode_length
+        assert self.env.name
+        self.name = self.env.name
+
+        obs = self.obs_at_reset()
+        self.env.observation_space = obs_dict_to_spaces(obs)
+        assert set(self.env.observation_space.keys()) == set(self.env.action_space.keys())
+
+        self.env_backend = env_backend
+        if hasattr(self.env, "env_backend"):
+            self.env.env_backend = env_backend
+        self.reset_on_host = True  # the first reset is on the host, later ones on the device
+        if env_backend == "cpu":
+            return
+
+        # ------------------------------------------------------------- device set-up
+        from warp_drive_amd.managers.data_manager import HIPDataManager
+        from warp_drive_amd.managers.function_manager import HIPEnvironmentReset, HIPFunctionManager
+
+        assert isinstance(self.env, CUDAEnvironmentContext), (
+            "the hip backend requires the environment to be an instance of CUDAEnvironmentContext")
+        assert num_envs >= 1
+        self.n_envs = num_envs
+        self.blocks_per_env = 1 if blocks_per_env is None else blocks_per_env
+        self.cuda_data_manager = HIPDataManager(num_agents=self.n_agents, episode_length=self.episode_length,
+                                                num_envs=self.n_envs, blocks_per_env=self.blocks_per_env,
+                                                device_id=process_id)
+        self.cuda_function_manager = HIPFunctionManager(
+            num_agents=int(self.cuda_data_manager.meta_info("n_agents")),
+            num_envs=int(self.cuda_data_manager.meta_info("n_envs")),
+            blocks_per_env=int(self.cuda_data_manager.meta_info("blocks_per_env")), process_id=process_id)
+        if testing_mode:
+            self.cuda_function_manager.load_hip_from_binary_file(testing_bin_filename)
+        else:
+            self.cuda_function_manager.compile_and_load_hip(env_name=self.name,
+                                                            customized_env_registrar=env_registrar,
+                                                            event_messenger=event_messenger)
+        self.cuda_function_feed = CUDAFunctionFeed(self.cuda_data_manager)
+        ready = self.env.initialize_step_function_context(
+            cuda_data_manager=self.cuda_data_manager, cuda_function_manager=self.cuda_function_manager,
+            cuda_step_function_feed=self.cuda_function_feed, step_function_name=f"Hip{self.name}Step")
+        assert ready, "The environment class failed to initialize the HIP step function"
+        self.env_resetter = HIPEnvironmentReset(function_manager=self.cuda_function_manager)
+        self.env_resetter.register_custom_reset_function(self.cuda_data_manager,
+                                                         reset_function_name=f"Hip{self.name}Reset")
+
+    # ------------------------------------------------------------------------- reset
+    def _push_initial_data(self):
+        def replicate(array):
+            return np.stack([array for _ in range(self.n_envs)], axis=0)
+
+        data = self.env.get_data_dictionary()
+        tensors = self.env.get_tensor_dictionary()
+        pools = self.env.get_reset_pool_dictionary()
+        for feed in (data, tensors):
+            for key in feed:
+                if feed[key]["attributes"]["save_copy_and_apply_at_reset"]:
+                    feed[key]["data"] = replicate(feed[key]["data"])
+        for key in pools:
+            if not pools[key]["attributes"].get("is_reset_pool", False):
+                continue
+            target = pools[key]["attributes"]["reset_target"]
+            owner = data if target in data else tensors if target in tensors else None
+            if owner is None:
+                raise Exception(f"Fail to locate the target data {target} for the reset pool "
+                                f"in neither data_dictionary nor tensor_dictionary")
+            assert not owner[target]["attributes"]["save_copy_and_apply_at_reset"]
+            owner[target]["data"] = replicate(owner[target]["data"])
+        self.cuda_data_manager.push_data_to_device(data)
+        self.cuda_data_manager.push_data_to_device(tensors, torch_accessible=True)
+        self.cuda_data_manager.push_data_to_device(pools)
+
+    def reset_all_envs(self):
+        self.env.timestep = 0
+        if self.reset_on_host:
+            obs = self.obs_at_reset()
+        else:
+            assert self.env_backend != "cpu"
+        if self.env_backend == "cpu":
+            return obs
+        if self.reset_on_host:
+            self._push_initial_data()
+            self.reset_on_host = False
+            return obs
+        self.env_resetter.reset_when_done(self.cuda_data_manager, mode="force_reset")
+        return {}
+
+    def init_reset_pool(self, seed=None):
+        self.env_resetter.init_reset_pool(self.cuda_data_manager, seed)
+
+    def reset_only_done_envs(self, undo_done_after_reset=True):
+        assert self.env_backend != "cpu" and not self.reset_on_host, (
+            "reset_only_done_envs() only works for the hip backend after the first reset")
+        self.env_resetter.reset_when_done(self.cuda_data_manager, mode="if_done",
+                                          undo_done_after_reset=undo_done_after_reset)
+        return {}
+
+    def custom_reset_all_envs(self, args=None, block=None, grid=None):
+        self.env_resetter.custom_reset(args=args, block=block, grid=grid)
+        return {}
+
+    # -------------------------------------------------------------------------- step
+    def step_all_envs(self, actions=None):
+        if self.env_backend != "cpu":
+            self.env.step()
+            return None
+        assert actions is not None, "Please provide actions to step with."
+        return self.env.step(actions)
+
+    def obs_at_reset(self):
+        return self.env.reset()
+
+    # gym-style aliases
+    def reset(self):
+        return self.reset_all_envs()
+
+    def step(self, actions=None):
+        return self.step_all_envs(actions)

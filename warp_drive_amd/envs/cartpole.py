@@ -1,0 +1,141 @@
+"""ClassicControl CartPole, single agent per replica (BASELINE config 5).
+
+Host-side mirror of reference example_envs/single_agent/classic_control/cartpole/
+cartpole.py:19-141 and single_agent/base.py.  The reference's CPU step delegates to
+third-party `gym.envs.classic_control.CartPoleEnv` (absent here); this class carries the
+classic constants itself and its CPU step is the same Euler update the reference's device
+kernel implements (cartpole_step_numba.py:29-83).  Parity for Cartpole is therefore
+"unpinned" (DESIGN.md).  The device step launches `HipClassicControlCartPoleEnvStep`.
+"""
+import math
+
+import numpy as np
+
+from warp_drive_amd.utils import spaces
+from warp_drive_amd.utils.constants import Constants
+from warp_drive_amd.utils.data_feed import DataFeed
+from warp_drive_amd.utils.gpu_environment_context import CUDAEnvironmentContext
+
+_OBSERVATIONS = Constants.OBSERVATIONS
+_ACTIONS = Constants.ACTIONS
+_REWARDS = Constants.REWARDS
+
+
+class CartPolePhysics:
+    """The constants of gym's CartPoleEnv (classic_control/cartpole.py in gym >= 0.26)."""
+    gravity = 9.8
+    masscart = 1.0
+    masspole = 0.1
+    length = 0.5  # half the pole's length
+    force_mag = 10.0
+    tau = 0.02
+    theta_threshold_radians = 12 * 2 * math.pi / 360
+    x_threshold = 2.4
+
+
+def euler_step(state, action, p=CartPolePhysics):
+    """One Euler tick with the dtype flow of the reference's Numba kernel
+    (float32 state/scalars; the 4.0/3.0 literal widens thetaacc/xacc to float64)."""
+    f32 = np.float32
+    x, x_dot, theta, theta_dot = (f32(v) for v in state)
+    force = f32(p.force_mag) if action > 0.5 else f32(-p.force_mag)
+    costheta, sintheta = np.cos(theta), np.sin(theta)  # numpy float32 kernels
+    total_mass = f32(p.masspole + p.masscart)
+    polemass_length = f32(p.masspole * p.length)
+    temp = f32(f32(force + f32(f32(polemass_length * f32(theta_dot * theta_dot)) * sintheta)) / total_mass)
+    den = np.float64(f32(p.length)) * (4.0 / 3.0 - np.float64(f32(f32(f32(p.masspole) * f32(costheta * costheta)) / total_mass)))
+    thetaacc = np.float64(f32(f32(f32(p.gravity) * sintheta) - f32(costheta * temp))) / den
+    xacc = np.float64(temp) - np.float64(polemass_length) * thetaacc * np.float64(costheta) / np.float64(total_mass)
+    tau = f32(p.tau)
+    nx = f32(x + f32(tau * x_dot))
+    nx_dot = f32(np.float64(x_dot) + np.float64(tau) * xacc)
+    ntheta = f32(theta + f32(tau * theta_dot))
+    ntheta_dot = f32(np.float64(theta_dot) + np.float64(tau) * thetaacc)
+    return np.array([nx, nx_dot, ntheta, ntheta_dot], dtype=f32)
+
+
+class ClassicControlCartPoleEnv:
+    name = "ClassicControlCartPoleEnv"
+
+    def __init__(self, episode_length=500, env_backend="cpu", reset_pool_size=0, seed=None):
+        self.num_agents = 1
+        self.agents = {0: True}
+        assert episode_length > 0
+        self.episode_length = episode_length
+        self.env_backend = env_backend
+        self.reset_pool_size = reset_pool_size
+        self.seed = seed
+        self.timestep = None
+        self.physics = CartPolePhysics
+        self._rng = np.random.default_rng(seed)
+        high = np.array([self.physics.x_threshold * 2, np.finfo(np.float32).max,
+                         self.physics.theta_threshold_radians * 2, np.finfo(np.float32).max], dtype=np.float32)
+        self.action_space = {0: spaces.Discrete(2)}
+        self.observation_space = {0: spaces.Box(-high, high, dtype=np.float32)}
+        self.state = None
+
+    def _draw_initial_state(self, fixed):
+        rng = np.random.default_rng(self.seed) if fixed else self._rng
+        return rng.uniform(low=-0.05, high=0.05, size=(4,)).astype(np.float32)
+
+    def reset(self):
+        self.timestep = 0
+        self.state = self._draw_initial_state(fixed=self.reset_pool_size < 2)
+        return {0: self.state.copy()}
+
+    def step(self, action=None):
+        self.timestep += 1
+        assert isinstance(action, dict) and len(action) == 1
+        self.state = euler_step(self.state, action[0], self.physics)
+        x, theta = self.state[0], self.state[2]
+        p = self.physics
+        terminated = bool(x < -p.x_threshold or x > p.x_threshold or theta < -p.theta_threshold_radians
+                          or theta > p.theta_threshold_radians)
+        done = {"__all__": self.timestep >= self.episode_length or terminated}
+        return {0: self.state.copy()}, {0: 1.0}, done, {}
+
+
+class CUDAClassicControlCartPoleEnv(ClassicControlCartPoleEnv, CUDAEnvironmentContext):
+    def __init__(self, *args, **kwargs):
+        ClassicControlCartPoleEnv.__init__(self, *args, **kwargs)
+        CUDAEnvironmentContext.__init__(self)
+
+    def get_data_dictionary(self):
+        p = self.physics
+        feed = DataFeed()
+        initial_state = self._draw_initial_state(fixed=True)
+        feed.add_data(name="state", data=np.atleast_2d(initial_state),
+                      save_copy_and_apply_at_reset=self.reset_pool_size < 2)
+        feed.add_data_list([
+            ("gravity", p.gravity), ("masspole", p.masspole), ("total_mass", p.masspole + p.masscart),
+            ("length", p.length), ("polemass_length", p.masspole * p.length), ("force_mag", p.force_mag),
+            ("tau", p.tau), ("theta_threshold_radians", p.theta_threshold_radians),
+            ("x_threshold", p.x_threshold),
+        ])
+        return feed
+
+    def get_reset_pool_dictionary(self):
+        pool = DataFeed()
+        if self.reset_pool_size >= 2:
+            states = np.stack([np.atleast_2d(self._draw_initial_state(fixed=False))
+                               for _ in range(self.reset_pool_size)], axis=0)
+            assert states.ndim == 3 and states.shape[2] == 4
+            pool.add_pool_for_reset(name="state_reset_pool", data=states, reset_target="state")
+        return pool
+
+    _STEP_ARGS = ["state", _ACTIONS, "_done_", _REWARDS, _OBSERVATIONS, "gravity", "masspole", "total_mass",
+                  "length", "polemass_length", "force_mag", "tau", "theta_threshold_radians", "x_threshold",
+                  "_timestep_", ("episode_length", "meta"), ("n_envs", "meta")]
+
+    def step_launch(self):
+        n_envs = int(self.cuda_data_manager.meta_info("n_envs"))
+        block = (256, 1, 1)
+        grid = (max(1, min(4096, (n_envs + 255) // 256)), 1)
+        return self.cuda_step, self.cuda_step_function_feed(self._STEP_ARGS), block, grid, 0
+
+    def step(self, actions=None):
+        self.timestep += 1
+        if self.env_backend != "hip":
+            raise Exception("CUDAClassicControlCartPoleEnv expects env_backend = 'hip'")
+        fn, args, block, grid, shared = self.step_launch()
+        fn(*args, block=block, grid=grid, shared=shared)

@@ -1,0 +1,213 @@
+"""TagGridWorld: N taggers chase one runner on an integer grid.
+
+Host-side mirror of reference example_envs/tag_gridworld/tag_gridworld.py
+(`TagGridWorld` :22-317, `CUDATagGridWorld` :320-380,
+`CUDATagGridWorldWithResetPool` :383-475): same constructor, same reset()/step()
+contract, same DataFeed registration; the device step launches the gfx950 kernel
+`HipTagGridWorldStep` (csrc/kernels/tag_gridworld.hip) instead of the CUDA/Numba ones.
+"""
+import numpy as np
+
+from warp_drive_amd.utils import spaces
+from warp_drive_amd.utils.constants import Constants
+from warp_drive_amd.utils.data_feed import DataFeed
+from warp_drive_amd.utils.gpu_environment_context import CUDAEnvironmentContext
+
+_OBSERVATIONS = Constants.OBSERVATIONS
+_ACTIONS = Constants.ACTIONS
+_REWARDS = Constants.REWARDS
+_LOC_X = "loc_x"
+_LOC_Y = "loc_y"
+
+
+class TagGridWorld:
+    """CPU environment (one replica)."""
+
+    name = "TagGridWorld"
+
+    def __init__(self, num_taggers=10, grid_length=10, episode_length=100, starting_location_x=None,
+                 starting_location_y=None, seed=None, wall_hit_penalty=0.1, tag_reward_for_tagger=10.0,
+                 tag_penalty_for_runner=2.0, step_cost_for_tagger=0.01, use_full_observation=True,
+                 env_backend="cpu"):
+        assert num_taggers > 0 and episode_length > 0
+        self.num_taggers = num_taggers
+        self.num_agents = num_taggers + 1  # the last agent is the only runner (:65-66)
+        self.episode_length = episode_length
+        self.grid_length = grid_length
+        self.np_random = np.random
+        if seed is not None:
+            self.seed(seed)
+        # type 0 = tagger, 1 = runner (:81-87)
+        self.agent_type = {a: int(a >= num_taggers) for a in range(self.num_agents)}
+        self.taggers = {a: True for a in range(num_taggers)}
+        self.runners = {self.num_agents - 1: True}
+        if starting_location_x is None:
+            assert starting_location_y is None
+            centre = int(0.5 * grid_length)  # taggers start in the centre, the runner at (0, 0)
+            starting_location_x = centre * np.ones(self.num_agents)
+            starting_location_y = centre * np.ones(self.num_agents)
+            starting_location_x[-1] = 0
+            starting_location_y[-1] = 0
+        else:
+            assert len(starting_location_x) == self.num_agents
+            assert len(starting_location_y) == self.num_agents
+        self.starting_location_x = starting_location_x
+        self.starting_location_y = starting_location_y
+        # no-op, right, left, up, down
+        self.step_actions = np.array([[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1]])
+        self.observation_space = None  # filled in by EnvWrapper
+        self.action_space = {a: spaces.Discrete(len(self.step_actions)) for a in range(self.num_agents)}
+        self.timestep = None
+        self.global_state = None
+        self.wall_hit_penalty = wall_hit_penalty
+        self.tag_reward_for_tagger = tag_reward_for_tagger
+        self.tag_penalty_for_runner = tag_penalty_for_runner
+        self.step_cost_for_tagger = step_cost_for_tagger
+        self.use_full_observation = use_full_observation
+        self.env_backend = env_backend
+
+    def seed(self, seed=None):
+        self.np_random.seed(seed)
+        return [seed]
+
+    # ---------------------------------------------------------------- host reset / step
+    def reset(self):
+        self.timestep = 0
+        T1 = self.episode_length + 1
+        self.global_state = {
+            _LOC_X: np.zeros((T1, self.num_agents), dtype=np.int32),
+            _LOC_Y: np.zeros((T1, self.num_agents), dtype=np.int32),
+        }
+        self.global_state[_LOC_X][0] = self.starting_location_x
+        self.global_state[_LOC_Y][0] = self.starting_location_y
+        return self.generate_observation()
+
+    def generate_observation(self):
+        n, L, t = self.num_agents, self.grid_length, self.timestep
+        x = self.global_state[_LOC_X][t]
+        y = self.global_state[_LOC_Y][t]
+        time = float(t) / self.episode_length
+        types = np.array([self.agent_type[a] for a in range(n)])
+        obs = {}
+        if self.use_full_observation:
+            shared = np.concatenate([x / L, y / L, types])
+            for a in range(n):
+                me = np.zeros(n)
+                me[a] = 1
+                obs[a] = np.concatenate([shared, me, [time]])
+            return obs
+        # partial: own cell, the other side's cell (runner for taggers, closest tagger for the runner)
+        d2 = np.square(x[:-1] - x[-1]) + np.square(y[:-1] - y[-1])
+        closest = int(np.argmin(d2))
+        for a in range(n):
+            o = n - 1 if a < n - 1 else closest
+            obs[a] = np.array([x[a] / L, y[a] / L, x[o] / L, y[o] / L, self.agent_type[a], time])
+        return obs
+
+    def step(self, actions=None):
+        self.timestep += 1
+        assert isinstance(actions, dict) and len(actions) == self.num_agents
+        n, L, t = self.num_agents, self.grid_length, self.timestep
+        moves = self.step_actions[[actions[a] for a in range(n)]]
+        x = self.global_state[_LOC_X][t - 1] + moves[:, 0]
+        y = self.global_state[_LOC_Y][t - 1] + moves[:, 1]
+        cx, cy = np.clip(x, 0, L), np.clip(y, 0, L)
+        hit_wall = (x != cx) | (y != cy)
+        self.global_state[_LOC_X][t] = cx
+        self.global_state[_LOC_Y][t] = cy
+        tag = bool(((cx[:-1] == cx[-1]) & (cy[:-1] == cy[-1])).any())
+        reward = np.empty(n)
+        reward[:-1] = self.tag_reward_for_tagger if tag else -1.0 * self.step_cost_for_tagger
+        reward[-1] = -1.0 * self.tag_penalty_for_runner if tag else 1.0 * self.step_cost_for_tagger
+        reward = reward + (-1.0 * self.wall_hit_penalty * hit_wall)
+        rew = {a: reward[a] for a in range(n)}
+        obs = self.generate_observation()
+        done = {"__all__": t >= self.episode_length or tag}
+        return obs, rew, done, {}
+
+
+_STEP_ARGS = [
+    _LOC_X, _LOC_Y, _ACTIONS, "_done_", _REWARDS, _OBSERVATIONS, "wall_hit_penalty",
+    "tag_reward_for_tagger", "tag_penalty_for_runner", "step_cost_for_tagger", "use_full_observation",
+    "world_boundary", "_timestep_", ("episode_length", "meta"), ("n_agents", "meta"), ("n_envs", "meta"),
+]
+
+
+class _DeviceStepMixin(CUDAEnvironmentContext):
+    """Device step: one launch of HipTagGridWorldStep over all replicas."""
+
+    def _scalar_feed(self):
+        return [
+            ("wall_hit_penalty", self.wall_hit_penalty),
+            ("tag_reward_for_tagger", self.tag_reward_for_tagger),
+            ("tag_penalty_for_runner", self.tag_penalty_for_runner),
+            ("step_cost_for_tagger", self.step_cost_for_tagger),
+            ("use_full_observation", self.use_full_observation),
+            ("world_boundary", self.grid_length),
+        ]
+
+    def step_launch(self):
+        """(function, args, block, grid, shared_bytes) of one device tick."""
+        fm = self.cuda_function_manager
+        epb, block, grid = fm.packed_geometry(self.num_agents, max_threads=256)
+        shared = 4 * (2 * epb * self.num_agents + 3 * epb)
+        return self.cuda_step, self.cuda_step_function_feed(_STEP_ARGS), block, grid, shared
+
+    def step(self, actions=None):
+        self.timestep += 1
+        if self.env_backend != "hip":
+            raise Exception(f"{type(self).__name__} expects env_backend = 'hip'")
+        fn, args, block, grid, shared = self.step_launch()
+        fn(*args, block=block, grid=grid, shared=shared)
+
+
+class CUDATagGridWorld(TagGridWorld, _DeviceStepMixin):
+    """Device version (reference :320-380); the class name is kept for drop-in use."""
+
+    def __init__(self, *args, **kwargs):
+        TagGridWorld.__init__(self, *args, **kwargs)
+        CUDAEnvironmentContext.__init__(self)
+
+    def get_data_dictionary(self):
+        feed = DataFeed()
+        for key in (_LOC_X, _LOC_Y):
+            feed.add_data(name=key, data=self.global_state[key][0], save_copy_and_apply_at_reset=True,
+                          log_data_across_episode=True)
+        feed.add_data_list(self._scalar_feed())
+        return feed
+
+
+class CUDATagGridWorldWithResetPool(TagGridWorld, _DeviceStepMixin):
+    """Device version whose replicas restart from a random member of a pool (reference :383-475)."""
+
+    POOL_SIZE = 5  # hard-coded in the reference too (:429)
+
+    def __init__(self, *args, **kwargs):
+        TagGridWorld.__init__(self, *args, **kwargs)
+        CUDAEnvironmentContext.__init__(self)
+
+    def get_data_dictionary(self):
+        feed = DataFeed()
+        for key in (_LOC_X, _LOC_Y):
+            feed.add_data(name=key, data=self.global_state[key][0], save_copy_and_apply_at_reset=False,
+                          log_data_across_episode=False)
+        feed.add_data_list(self._scalar_feed())
+        return feed
+
+    def get_reset_pool_dictionary(self):
+        L = int(self.grid_length)
+        cells = np.linspace(1, L - 1, L - 1)
+
+        def draw():
+            v = self.np_random.choice(cells, self.num_agents).astype(np.int32)
+            v[-1] = 0  # the runner always restarts in the corner
+            return v
+
+        xs, ys = [], []
+        for _ in range(self.POOL_SIZE):
+            xs.append(draw())
+            ys.append(draw())
+        pool = DataFeed()
+        pool.add_pool_for_reset(name=f"{_LOC_X}_reset_pool", data=np.stack(xs), reset_target=_LOC_X)
+        pool.add_pool_for_reset(name=f"{_LOC_Y}_reset_pool", data=np.stack(ys), reset_target=_LOC_Y)
+        return pool

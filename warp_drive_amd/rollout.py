@@ -1,0 +1,82 @@
+"""Device-resident rollout tick: sample every action head -> env step -> reset finished
+replicas, with no host round trip between the launches.
+
+The reference drives the same sequence from Python with one driver call per kernel, a
+device->host sync on the done flags and three synchronisations per tick
+(warp_drive/training/trainers/trainer_base.py:392-426; per reset it issues one launch
+per registered array, pycuda_function_manager.py:686-753).  Here the whole tick is a
+fixed LaunchPlan replayed from C (or captured once into a hipGraph):
+
+    sample_actions(head 0) ... sample_actions(head H-1)   writes [E, n, H] actions directly
+    Hip<Env>Step                                          obs / rewards / done in place
+    reset_when_done_fused                                 every array + done/timestep, 1 launch
+
+The probability tensors the sampler reads are whatever the policy wrote last (torch
+tensors aliased in place); for kernel-only throughput they are constant uniform tensors.
+"""
+import numpy as np
+import torch
+
+from warp_drive_amd.managers import hip_driver as drv
+from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+from warp_drive_amd.utils.constants import Constants
+from warp_drive_amd.utils.spaces import Discrete, MultiDiscrete
+
+_ACTIONS = Constants.ACTIONS
+
+
+class RolloutEngine:
+    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True):
+        """probabilities: list (one per action head) of contiguous float32 CUDA tensors
+        [n_envs, n_agents, n_actions_of_head]; None = uniform."""
+        assert env_wrapper.env_backend == "hip"
+        self.w = env_wrapper
+        self.sampler = sampler
+        dm = env_wrapper.cuda_data_manager
+        E, N = env_wrapper.n_envs, env_wrapper.n_agents
+        space = env_wrapper.env.action_space[0]
+        if isinstance(space, MultiDiscrete):
+            head_sizes = [int(v) for v in space.nvec]
+        elif isinstance(space, Discrete):
+            head_sizes = [int(space.n)]
+        else:
+            raise NotImplementedError("RolloutEngine drives discrete action spaces")
+        dev = dm.data_on_device_via_torch(_ACTIONS).device
+        if probabilities is None:
+            probabilities = [torch.full((E, N, a), 1.0 / a, dtype=torch.float32, device=dev) for a in head_sizes]
+        assert len(probabilities) == len(head_sizes)
+        for p, a in zip(probabilities, head_sizes):
+            assert p.is_contiguous() and p.dtype == torch.float32 and tuple(p.shape) == (E, N, a)
+        self.probabilities = probabilities
+        self.head_sizes = head_sizes
+        self.plan = drv.LaunchPlan()
+        actions = dm.device_data(_ACTIONS)  # [E, N, H] int32 (H = 1 for Discrete)
+        H = len(head_sizes)
+        self.entry_names = []
+        for k, (p, a) in enumerate(zip(probabilities, head_sizes)):
+            fn, args, block, grid, shared = sampler.categorical_launch(
+                p, actions, E * N, a, False, _stream_tag(f"{_ACTIONS}_{k}"), out_stride=H, out_offset=k)
+            self.plan.add(fn, args, block, grid, shared)
+            self.entry_names.append(f"sample_actions[{k}]")
+        fn, args, block, grid, shared = env_wrapper.env.step_launch()
+        self.plan.add(fn, args, block, grid, shared)
+        self.step_entry = len(self.entry_names)
+        self.step_kernel_name = fn.name
+        self.entry_names.append(fn.name)
+        if reset_done:
+            fn, args, block, grid = env_wrapper.env_resetter.fused_launch(dm, np.int32(0), 1)
+            self.plan.add(fn, args, block, grid, 0)
+            self.entry_names.append(fn.name)
+        self._graph_ticks = 0
+
+    def run(self, ticks, stream=None):
+        """Enqueue `ticks` rollout ticks (asynchronous)."""
+        self.plan.run(ticks, stream)
+
+    def run_graph(self, ticks, ticks_per_graph=10, stream=None):
+        """Same, replaying a hipGraph that holds `ticks_per_graph` ticks."""
+        assert ticks % ticks_per_graph == 0
+        if self._graph_ticks != ticks_per_graph:
+            self.plan.instantiate_graph(ticks_per_graph, stream)
+            self._graph_ticks = ticks_per_graph
+        self.plan.run_graph(ticks // ticks_per_graph, stream)
