@@ -157,6 +157,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # hipGraph capture is not allowed on the legacy default stream: use a side stream there
+    side = torch.cuda.Stream() if args.mode == "graph" else None
+    if side is not None:
+        torch.cuda.set_stream(side)
     run(warmup)
     barrier()
     # sample the dominant kernel's duration with HIP events on the launch stream inside the

@@ -45,6 +45,7 @@ void set_err(const char *fmt, ...) {
   X(hipGetDeviceCount, hipError_t (*)(int *))                                                  \
   X(hipGetDevicePropertiesR0600, hipError_t (*)(hipDeviceProp_t *, int))                       \
   X(hipGetErrorString, const char *(*)(hipError_t))                                            \
+  X(hipGetLastError, hipError_t (*)(void))                                                     \
   X(hipMalloc, hipError_t (*)(void **, size_t))                                                \
   X(hipFree, hipError_t (*)(void *))                                                           \
   X(hipMemcpyAsync, hipError_t (*)(void *, const void *, size_t, hipMemcpyKind, hipStream_t))  \
@@ -109,6 +110,10 @@ int bind_runtime(const char *path) {
 
 inline int check(hipError_t e, const char *what) {
   if (e == hipSuccess) return 0;
+  // the runtime keeps a sticky per-thread "last error" that other users of the same runtime
+  // (PyTorch checks it after its own launches) would trip over: this failure is reported
+  // through our return code, so consume it here.
+  if (g_hip.hipGetLastError) (void)g_hip.hipGetLastError();
   set_err("%s failed: %s (%d)", what, g_hip.hipGetErrorString ? g_hip.hipGetErrorString(e) : "?",
           static_cast<int>(e));
   return static_cast<int>(e);

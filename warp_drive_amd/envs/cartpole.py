@@ -95,7 +95,7 @@ class ClassicControlCartPoleEnv:
         return {0: self.state.copy()}, {0: 1.0}, done, {}
 
 
-class CUDAClassicControlCartPoleEnv(ClassicControlCartPoleEnv, CUDAEnvironmentContext):
+class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPoleEnv):
     def __init__(self, *args, **kwargs):
         ClassicControlCartPoleEnv.__init__(self, *args, **kwargs)
         CUDAEnvironmentContext.__init__(self)

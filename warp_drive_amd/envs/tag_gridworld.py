@@ -161,7 +161,7 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         fn(*args, block=block, grid=grid, shared=shared)
 
 
-class CUDATagGridWorld(TagGridWorld, _DeviceStepMixin):
+class CUDATagGridWorld(_DeviceStepMixin, TagGridWorld):
     """Device version (reference :320-380); the class name is kept for drop-in use."""
 
     def __init__(self, *args, **kwargs):
@@ -177,7 +177,7 @@ class CUDATagGridWorld(TagGridWorld, _DeviceStepMixin):
         return feed
 
 
-class CUDATagGridWorldWithResetPool(TagGridWorld, _DeviceStepMixin):
+class CUDATagGridWorldWithResetPool(_DeviceStepMixin, TagGridWorld):
     """Device version whose replicas restart from a random member of a pool (reference :383-475)."""
 
     POOL_SIZE = 5  # hard-coded in the reference too (:429)
