@@ -6,30 +6,48 @@
 // Where the reference's own CUDA kernel (tag_continuous_step_pycuda.cu:351-520)
 // disagrees with its CPU step the CPU wins: stable (distance, id) neighbour order,
 // tag counts accumulated without races, no end-of-game bonus for a runner tagged out
-// on the last tick.  Argument order is the reference kernel's (:351-385) plus a
-// trailing n_envs; the two O(N^2) global scratch arrays it sorts in HBM
+// on the last tick.  Argument order is the reference kernel's (:351-385) plus trailing
+// n_envs and the two action-table lengths; the two O(N^2) global scratch arrays it sorts in HBM
 // (neighbor_distances, neighbor_ids_sorted_by_distance; :167-199) are accepted and
 // never touched.
 //
-// MI355X mapping
-//   * a block packs `epb` consecutive replicas so that epb*N fills whole wavefronts
-//     (N = 105: 3 replicas = 315 of 320 lanes); thread t serves agent t % N of local
-//     replica t / N.  The reference geometry block=(N,1,1), grid=(E,1) is epb = 1.
-//   * phase 0  coalesced [E,N] loads, float32 kinematics (numpy-exact cos/sin),
-//              coalesced stores, post-move state staged in LDS (positions in float32
-//              for distances, normalised features as the reference computes them:
-//              x,y in float64, speed/acc/dir in float32).
-//   * phase 1  K nearest neighbours per agent entirely in registers: candidates are
-//              streamed from LDS (wave-uniform address => broadcast, conflict-free) in
-//              id order and inserted into a sorted register list; strict '<' makes
-//              ties resolve to the lower id, i.e. heapq.nsmallest's stable order.
-//   * phase 2  the packed replicas' observation block is contiguous in HBM; it is
-//              produced by a block-strided gather from LDS so every store instruction
-//              writes 64 consecutive floats (the reference writes one 284-byte-strided
-//              row per thread).
-//   * phase 3  rewards: each runner scans the taggers (first minimum wins), tag counts
-//              go through LDS atomics, float adds are replayed in the CPU's order.
+// MI355X mapping (one block = `epb` consecutive replicas, thread t = agent t % N of
+// local replica t / N; N = 105 -> 3 replicas fill 315 of 320 lanes; the reference
+// geometry block=(N,1,1), grid=(E,1) is simply epb = 1):
+//   phase 0  coalesced [E,N] loads, float32 kinematics (numpy-exact cos/sin), coalesced
+//            stores; post-move state staged in LDS: float32 positions for distances and
+//            the seven observation features per agent as float64 (x,y normalised in
+//            float64, speed/acc/dir normalised in float32 then widened -- exactly the
+//            reference's dtype flow, so the float64 neighbour difference is bit-exact).
+//   phase 1  K nearest neighbours, ~28 VALU ops per candidate instead of a 50-op sorted
+//            insertion:
+//              A. stream all N candidates from LDS (wave-uniform address: broadcast) and
+//                 keep only the K+1 smallest SQUARED distances in registers with a
+//                 v_med3_f32 chain (B[k] = med3(B[k-1], B[k], d2): one op per slot, no
+//                 compares, no ids, no serial dependency);
+//              B. B[K] bounds the K-th neighbour.  Convert it to the float32 distance S
+//                 the reference compares (sqrt rounds, so a RANGE [T2lo, T2hi] of squared
+//                 distances maps to S), stream the candidates again and append the ones
+//                 below the range, plus the first few inside it in id order, to a
+//                 K-entry list in LDS -- exactly the reference's K smallest (distance, id)
+//                 keys;
+//              C. sort those <= K entries by (sqrt(d2), id) with a register sorting
+//                 network and leave the ids in LDS.
+//   phase 2  the packed replicas' observation block is contiguous in HBM ([E,N,F]); it
+//            is produced by a block-strided gather from LDS -- every store instruction
+//            writes 64 consecutive floats (the reference writes one 284-byte-strided row
+//            per thread); (feature, slot) of a column comes from a small LDS table and
+//            the (replica, agent, column) counters advance incrementally: no divisions.
+//   phase 3  rewards: each runner scans the taggers (first minimum wins), tag counts go
+//            through LDS atomics, float adds are replayed in the CPU's order.
 #include "wd_common.h"
+
+// Timing experiments only (scripts/ablate_tc.sh): bit 0 skips phase 1 (neighbour search),
+// bit 1 skips phase 2 (observation gather), bit 2 stops phase 1 after part A, bit 3 after
+// part B.  Results are wrong when any bit is set; the shipped code object uses 0.
+#ifndef WD_TC_ABLATE
+#define WD_TC_ABLATE 0
+#endif
 
 namespace {
 
@@ -56,82 +74,263 @@ struct TcArgs {
   int N, T, E;
 };
 
-// LDS carve-up for `epb` packed replicas (all offsets multiples of 8 bytes).
-struct TcLds {
-  double *nx, *ny;               // [epb*N] normalised positions (float64, :454)
-  float *x, *y;                  // [epb*N] positions after the move
-  float *nsp, *nac, *ndir;       // [epb*N] normalised speed / acceleration / direction
-  int *sig;                      // [epb*N] still_in_the_game BEFORE this tick's tagging
-  int *tagcnt;                   // [epb*N] tags credited to a tagger this tick
-  int *types;                    // [N]
-  int *tagger_ids;               // [N] ids of taggers, ascending
-  int *nbr;                      // [epb*N*K] neighbour ids, -1 = padding
-  int *tstep, *nrun, *ntag;      // [epb], [epb], [1]
+struct TcCand {
+  float d2;
+  int id;
 };
 
-__device__ __forceinline__ TcLds tc_carve(unsigned char *base, int epb, int N, int K) {
+// LDS carve-up for `epb` packed replicas, A = epb * N agents (offsets multiples of 8).
+struct TcLds {
+  double *feat;      // [7][A] nx, ny, nspeed, nacc, ndir, type, still_in_game(before tagging)
+  TcCand *cand;      // [A][K+1] phase-1 lists; afterwards the first K ints of a row = neighbour ids
+  float *x, *y;      // [A] positions after the move (x = +BIG for agents out of the game)
+  int *sig;          // [A] still_in_the_game before this tick's tagging
+  int *tagcnt;       // [A] tags credited to a tagger this tick
+  int *types;        // [N]
+  int *tagger_ids;   // [N] ascending
+  float *acc_tab, *turn_tab;  // action tables (n_acc, n_turn entries; capacity 64 each)
+  int *wave_cnt;     // [16] taggers per wavefront (rank computation)
+  int *tstep, *nrun; // [epb]
+  float *tfrac;      // [epb] float(t) / episode_length
+};
+
+#define WD_TC_TAB 64  // capacity of the LDS copies of the action tables
+
+__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K) {
   TcLds l;
-  const int A = epb * N;
-  unsigned char *p = base;
-  l.nx = (double *)p; p += sizeof(double) * A;
-  l.ny = (double *)p; p += sizeof(double) * A;
+  const size_t A = (size_t)epb * N;
+  l.feat = (double *)p; p += 8 * 7 * A;
+  l.cand = (TcCand *)p; p += 8 * A * (K + 1);
   l.x = (float *)p; p += 4 * A;
   l.y = (float *)p; p += 4 * A;
-  l.nsp = (float *)p; p += 4 * A;
-  l.nac = (float *)p; p += 4 * A;
-  l.ndir = (float *)p; p += 4 * A;
   l.sig = (int *)p; p += 4 * A;
   l.tagcnt = (int *)p; p += 4 * A;
-  l.types = (int *)p; p += 4 * N;
-  l.tagger_ids = (int *)p; p += 4 * N;
-  l.nbr = (int *)p; p += 4 * (size_t)A * K;
+  l.types = (int *)p; p += 4 * (size_t)N;
+  l.tagger_ids = (int *)p; p += 4 * (size_t)N;
+  l.acc_tab = (float *)p; p += 4 * WD_TC_TAB;
+  l.turn_tab = (float *)p; p += 4 * WD_TC_TAB;
+  l.wave_cnt = (int *)p; p += 4 * 16;
   l.tstep = (int *)p; p += 4 * epb;
   l.nrun = (int *)p; p += 4 * epb;
-  l.ntag = (int *)p; p += 4;
+  l.tfrac = (float *)p;
   return l;
 }
 
+#define WD_BIG 1.0e30f  // (x - BIG)^2 overflows to +inf: such a candidate is never selected
+
+// compare-exchange of (distance, id) keys, ascending.  distance >= 0, so its float bits order
+// like an unsigned integer and (bits << 32 | id) is one total 64-bit key.
+__device__ __forceinline__ void tc_cex(unsigned long long &a, unsigned long long &b) {
+  const bool swap = a > b;
+  const unsigned long long lo = swap ? b : a, hi = swap ? a : b;
+  a = lo;
+  b = hi;
+}
+
+// Batcher's merge-exchange sorting network (Knuth 5.2.2 Algorithm M) for n keys, built at
+// compile time and fully unrolled: 31 compare-exchanges for n = 10 (odd-even transposition
+// needs 45).
+template <int n>
+struct TcNet {
+  int a[n * 8 + 1] = {}, b[n * 8 + 1] = {};
+  int count = 0;
+};
+
+template <int n>
+constexpr TcNet<n> tc_make_net() {
+  TcNet<n> net;
+  int t = 0;
+  while ((1 << t) < n) ++t;
+  if (t == 0) return net;
+  for (int p = 1 << (t - 1); p > 0; p >>= 1) {
+    int q = 1 << (t - 1), r = 0, d = p;
+    for (;;) {
+      for (int i = 0; i + d < n; ++i)
+        if ((i & p) == r) { net.a[net.count] = i; net.b[net.count] = i + d; ++net.count; }
+      if (q == p) break;
+      d = q - p;
+      q >>= 1;
+      r = p;
+    }
+  }
+  return net;
+}
+
+template <int n>
+__device__ __forceinline__ void tc_sort_network(unsigned long long (&key)[n]) {
+  constexpr TcNet<n> net = tc_make_net<n>();
+#pragma unroll
+  for (int c = 0; c < net.count; ++c) tc_cex(key[net.a[c]], key[net.b[c]]);
+}
+
+// ---- phase 1, register-resident variant (K <= KMAX) --------------------------------
 template <int KMAX>
-__device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *smem) {
-  const int N = a.N, K = a.K;
+__device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag, int li, int N, int K) {
+  const float *cx = l.x + el * N, *cy = l.y + el * N;
+  TcCand *mine = l.cand + (size_t)li * (K + 1);
+  const float xi = cx[ag], yi = cy[ag];
+  const float INF = __builtin_inff();
+
+  // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
+  //    agents out of the game contribute +inf)
+  float B[KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k) B[k] = INF;
+  for (int j = 0; j < N; ++j) {
+    const float dx = xi - cx[j], dy = yi - cy[j];
+    const float d2 = dx * dx + dy * dy;
+#pragma unroll
+    for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], d2);
+    B[0] = fminf(B[0], d2);
+  }
+  if (WD_TC_ABLATE & 4) { ((float *)mine)[0] = B[KMAX]; return; }
+  // B[k], k = 1..K are the K smallest squared distances to OTHER agents (B[0] is self or a
+  // co-located twin).  T2 = the K-th of them.
+  float T2 = INF;
+#pragma unroll
+  for (int k = 1; k <= KMAX; ++k) T2 = (k == K) ? B[k] : T2;
+  // range of squared distances whose float32 sqrt equals S = sqrtf(T2)
+  float T2lo, T2hi;
+  if (T2 == INF) {          // fewer than K candidates in the game: take them all
+    T2lo = INF; T2hi = 3.0e38f;
+  } else if (T2 == 0.0f) {  // K twins at distance 0
+    T2lo = 0.0f; T2hi = 0.0f;
+  } else {
+    const float S = sqrtf(T2);
+    const float Sup = __uint_as_float(__float_as_uint(S) + 1u), Sdn = __uint_as_float(__float_as_uint(S) - 1u);
+    const double mhi = 0.5 * ((double)S + (double)Sup), mlo = 0.5 * ((double)S + (double)Sdn);
+    // sqrtf(x) == S  <=>  mlo^2 < x < mhi^2  (midpoints squared are exact in float64 and are
+    // never float32 values themselves)
+    const double hi2 = mhi * mhi, lo2 = mlo * mlo;
+    float th = (float)hi2, tl = (float)lo2;  // round to nearest, then step to the inside
+    if ((double)th > hi2) th = __uint_as_float(__float_as_uint(th) - 1u);
+    if ((double)tl < lo2) tl = __uint_as_float(__float_as_uint(tl) + 1u);
+    T2hi = th;
+    T2lo = tl;
+  }
+  int c_less = 0;  // others strictly below the range
+#pragma unroll
+  for (int k = 1; k <= KMAX; ++k) c_less += (k <= K && B[k] < T2lo) ? 1 : 0;
+  const int need_tie = K - c_less;
+
+  // B. collect the selected candidates in id order.  Branch-free: every candidate is written to
+  //    the next free slot and the slot only advances when it was selected (a row has K+1 slots,
+  //    so the write after the K-th selection stays inside the row).
+  int cnt = 0, tie_taken = 0;
+  for (int j = 0; j < N; ++j) {
+    const float dx = xi - cx[j], dy = yi - cy[j];
+    const float d2 = dx * dx + dy * dy;
+    const bool other = (j != ag);
+    const bool less = other && (d2 < T2lo);
+    const bool tie = other && !less && (d2 <= T2hi) && (tie_taken < need_tie);
+    mine[cnt] = TcCand{d2, j};
+    cnt += (less || tie) ? 1 : 0;
+    tie_taken += tie ? 1 : 0;
+  }
+  if (WD_TC_ABLATE & 8) return;
+
+  // C. order by (distance, id): 64-bit keys (float bits of sqrt(d2) << 32 | id)
+  unsigned long long key[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const bool have = k < cnt;
+    const TcCand c = mine[have ? k : 0];
+    const unsigned long long sbits = have ? (unsigned long long)__float_as_uint(sqrtf(c.d2)) : 0x7f800000ull;
+    key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? c.id : 0xffff);
+  }
+  tc_sort_network<KMAX>(key);
+  int *out = (int *)mine;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) out[k] = (key[k] >> 32) == 0x7f800000ull ? -1 : (int)(unsigned int)key[k];
+}
+
+// ---- phase 1, generic K: K passes, each picks the smallest (d, id) key above the previous
+__device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, int li, int N, int K) {
+  const float *cx = l.x + el * N, *cy = l.y + el * N;
+  const int *csig = l.sig + el * N;
+  int *out = (int *)(l.cand + (size_t)li * (K + 1));
+  const float xi = cx[ag], yi = cy[ag];
+  float pd = -1.0f;
+  int pj = -1;
+  for (int k = 0; k < K; ++k) {
+    float best = __builtin_inff();
+    int bj = -1;
+    for (int j = 0; j < N; ++j) {
+      if (csig[j] == 0 || j == ag) continue;
+      const float dx = xi - cx[j], dy = yi - cy[j];
+      const float d = sqrtf(dx * dx + dy * dy);
+      const bool above = (d > pd) || (d == pd && j > pj);
+      if (above && d < best) { best = d; bj = j; }
+    }
+    out[k] = bj;
+    if (bj < 0) {
+      for (int kk = k + 1; kk < K; ++kk) out[kk] = -1;
+      break;
+    }
+    pd = best;
+    pj = bj;
+  }
+}
+
+template <int KMAX>
+__device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *smem, int n_acc, int n_turn) {
+  const int N = a.N, K = a.use_full_obs ? 0 : a.K;
+  const int W = a.use_full_obs ? (N - 1) : K;  // columns per feature
+  const int F = 7 * W + 1;
   const int epb = max(1, (int)blockDim.x / N);
-  const TcLds l = tc_carve(smem, epb, N, a.use_full_obs ? 0 : K);
-  const int tid = threadIdx.x;
+  const int A = epb * N;
+  const TcLds l = tc_carve(smem, epb, N, K);
+  const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
-  const float two_pi = 6.2831854820251465f;          // float32(2*pi), :356
+  const int row_ints = 2 * (K + 1);                    // ints per agent row of the id list
+  const float two_pi = 6.2831854820251465f;            // float32(2*pi), :356
   const float L = a.grid_length;
   const double diag = (double)L * 1.4142135623730951;  // float32 L * np.sqrt(2) -> f64, :146
   const float sp_div = a.max_speed + 1.0e-10f;         // float32 + float32(eps), :456
-  const int F = a.use_full_obs ? 7 * (N - 1) + 1 : 7 * K + 1;
 
-  // agent types and the ascending tagger list are replica-independent
-  for (int i = tid; i < N; i += blockDim.x) l.types[i] = a.agent_types[i];
-  if (tid == 0) *l.ntag = 0;
-  __syncthreads();
-  for (int i = tid; i < N; i += blockDim.x) {
-    if (l.types[i] == 1) {
-      int rank = 0;
-      for (int j = 0; j < i; ++j) rank += (l.types[j] == 1);
-      l.tagger_ids[rank] = i;
-      atomicAdd(l.ntag, 1);
+  // ---- replica-independent tables: agent types, ascending tagger list, action tables
+  const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
+  if (tab_in_lds) {
+    for (int i = tid; i < n_acc; i += T_) l.acc_tab[i] = a.acc_actions[i];
+    for (int i = tid; i < n_turn; i += T_) l.turn_tab[i] = a.turn_actions[i];
+  }
+  {
+    // rank of a tagger = number of taggers with a smaller id: wave ballots + per-wave counts
+    const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
+    int n_taggers_before = 0;
+    for (int base = 0; base < N; base += T_) {  // one trip unless N > blockDim.x
+      const int i = base + tid;
+      const int ty = (i < N) ? a.agent_types[i] : 0;
+      if (i < N) l.types[i] = ty;
+      const unsigned long long m = __ballot(ty == 1);
+      if (lane == 0) l.wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int before = n_taggers_before;
+      for (int w2 = 0; w2 < wave; ++w2) before += l.wave_cnt[w2];
+      if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      for (int w2 = 0; w2 < n_waves; ++w2) n_taggers_before += l.wave_cnt[w2];
+      __syncthreads();
     }
+    if (tid == 0) l.wave_cnt[0] = n_taggers_before;
   }
   __syncthreads();
-  const int n_taggers = *l.ntag;
+  const int n_taggers = l.wave_cnt[0];
 
   for (int env0 = blockIdx.x * epb; env0 < a.E; env0 += gridDim.x * epb) {
     const int env = env0 + el;
     const bool active = (el < epb) && (env < a.E);
     const int gi = env * N + ag;  // index into [E, N] arrays
     const int li = el * N + ag;   // index into LDS arrays
-    float edge_pen = 0.0f;
+    float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
 
     // ------------------------------------------------------------ phase 0: move
     if (active) {
       const int sg = a.sig_arr[gi];
       const float s = (float)sg;
-      const int a_acc = a.actions[2 * gi + 0], a_turn = a.actions[2 * gi + 1];
-      const float d_acc = a.acc_actions[a_acc], d_turn = a.turn_actions[a_turn];
+      const int2 act = ((const int2 *)a.actions)[gi];
+      const float d_acc = tab_in_lds ? l.acc_tab[act.x] : a.acc_actions[act.x];
+      const float d_turn = tab_in_lds ? l.turn_tab[act.y] : a.turn_actions[act.y];
       const float dir = wd_np_remainderf(a.direction[gi] + d_turn, two_pi) * s;  // :355-357
       float acc = a.acceleration[gi] + d_acc;                                     // :359
       const float vmax = a.max_speed * a.skill_levels[ag];                        // :363
@@ -152,122 +351,102 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
       a.direction[gi] = dir;
       a.acceleration[gi] = acc;
       a.edge_pen_arr[gi] = edge_pen;
-      l.x[li] = px;
+      my_x = px;
+      my_y = py;
+      // agents out of the game are pushed to +BIG for the neighbour search only; every other
+      // consumer (taggers are never out of the game) reads real positions
+      l.x[li] = sg ? px : WD_BIG;
       l.y[li] = py;
-      l.nx[li] = (double)px / diag;   // :462
-      l.ny[li] = (double)py / diag;
-      l.nsp[li] = v / sp_div;
-      l.nac[li] = acc / sp_div;
-      l.ndir[li] = dir / two_pi;
+      l.feat[0 * A + li] = (double)px / diag;            // :462 (float64 division)
+      l.feat[1 * A + li] = (double)py / diag;
+      l.feat[2 * A + li] = (double)(v / sp_div);         // float32 division, then widened
+      l.feat[3 * A + li] = (double)(acc / sp_div);
+      l.feat[4 * A + li] = (double)(dir / two_pi);
+      l.feat[5 * A + li] = (double)l.types[ag];
+      l.feat[6 * A + li] = (double)sg;
       l.sig[li] = sg;
       l.tagcnt[li] = 0;
       if (ag == 0) {
         const int t = a.timestep[env] + 1;  // :800
         a.timestep[env] = t;
         l.tstep[el] = t;
+        l.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474
         l.nrun[el] = a.num_runners[env];
       }
     }
     __syncthreads();
 
     // ------------------------------------------------ phase 1: K nearest neighbours
-    if (!a.use_full_obs && active) {
-      int *my_nbr = l.nbr + (size_t)li * K;
+    if (!a.use_full_obs && active && !(WD_TC_ABLATE & 1)) {
       if (l.sig[li]) {
-        const float xi = l.x[li], yi = l.y[li];
-        const float *cx = l.x + el * N, *cy = l.y + el * N;
-        const int *csig = l.sig + el * N;
-        if (KMAX > 0) {
-          float bd[KMAX > 0 ? KMAX : 1];
-          int bi[KMAX > 0 ? KMAX : 1];
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k) { bd[k] = __builtin_inff(); bi[k] = -1; }
-          for (int j = 0; j < N; ++j) {
-            const float dx = xi - cx[j], dy = yi - cy[j];   // x[agent] - x[other], :411-417
-            float d = sqrtf(dx * dx + dy * dy);
-            d = (csig[j] != 0 && j != ag) ? d : __builtin_inff();
-#pragma unroll
-            for (int k = KMAX - 1; k >= 0; --k) {
-              const bool pk = d < bd[k];
-              const bool pkm1 = (k > 0) ? (d < bd[k > 0 ? k - 1 : 0]) : false;
-              bd[k] = pkm1 ? bd[k > 0 ? k - 1 : 0] : (pk ? d : bd[k]);
-              bi[k] = pkm1 ? bi[k > 0 ? k - 1 : 0] : (pk ? j : bi[k]);
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k)
-            if (k < K) my_nbr[k] = bi[k];
-        } else {
-          // generic K: K passes, each picks the smallest (d, id) key above the previous one
-          float pd = -1.0f;
-          int pj = -1;
-          for (int k = 0; k < K; ++k) {
-            float best = __builtin_inff();
-            int bj = -1;
-            for (int j = 0; j < N; ++j) {
-              if (csig[j] == 0 || j == ag) continue;
-              const float dx = xi - cx[j], dy = yi - cy[j];
-              const float d = sqrtf(dx * dx + dy * dy);
-              const bool above = (d > pd) || (d == pd && j > pj);
-              if (above && d < best) { best = d; bj = j; }
-            }
-            my_nbr[k] = bj;
-            if (bj < 0) { for (int kk = k + 1; kk < K; ++kk) my_nbr[kk] = -1; break; }
-            pd = best;
-            pj = bj;
-          }
-        }
+        if (KMAX > 0) tc_knn_registers<(KMAX > 0 ? KMAX : 1)>(l, el, ag, li, N, K);
+        else tc_knn_generic(l, el, ag, li, N, K);
       } else {
-        for (int k = 0; k < K; ++k) my_nbr[k] = -1;
+        int *out = (int *)(l.cand + (size_t)li * (K + 1));
+        for (int k = 0; k < K; ++k) out[k] = -1;
       }
     }
     __syncthreads();
 
-    // ------------------------------------------------ phase 2: observations (coalesced)
-    {
-      const int envs_here = min(epb, a.E - env0);
-      const int per_env = N * F;
-      const long obs_base = (long)env0 * per_env;
-      const int total = envs_here * per_env;
-      for (int q = tid; q < total; q += blockDim.x) {
-        const int e = q / per_env, r = q - e * per_env;
-        const int i = r / F, f = r - i * F;
-        const int eb = e * N;
-        const int me = eb + i;
-        const bool in_game = l.sig[me] != 0;
-        const int width = a.use_full_obs ? (N - 1) : K;
-        float v = 0.0f;
-        if (f == 7 * width) {
-          // time: float(t) / episode_length for agents in the game, else 0  (:474,:493,:543)
-          v = in_game ? (float)((double)l.tstep[e] / (double)a.T) : 0.0f;
+    // ------------------------------------------------ phase 2: observations
+    // One work item = (agent row m, neighbour slot k): it reads the neighbour id once, then
+    // the 7 features of that neighbour and of the agent, and writes the 7 columns
+    // {c*W + k} of the row.  Consecutive lanes hold consecutive k, so every store
+    // instruction writes runs of W consecutive floats (whole 256-byte lines in the
+    // full-observation mode); only two dependent LDS round trips per 7 outputs.
+    if (!(WD_TC_ABLATE & 2)) {
+      const int agents_here = min(epb, a.E - env0) * N;
+      const int items = agents_here * W;
+      float *obs_blk = a.obs + (long)env0 * N * F;
+      const int Wd = max(W, 1);
+      int k = tid % Wd, m = tid / Wd;         // block-local agent row and slot of the first item
+      int i = m % N;                          // agent id inside its replica
+      const int sk = T_ % Wd, sm = T_ / Wd, si = sm % N;
+      for (int t = tid; t < items; t += T_) {
+        const int ebase = m - i;              // first agent of this row's replica
+        const bool in_game = l.sig[m] != 0;
+        int j;
+        bool valid;
+        if (a.use_full_obs) {
+          j = k + (k >= i ? 1 : 0);
+          valid = true;   // type / still_in_game columns are filled even for agents out of the game
         } else {
-          const int c = f / width, k = f - c * width;
-          int j;
-          bool valid;
-          if (a.use_full_obs) {
-            j = k + (k >= i ? 1 : 0);
-            valid = true;
-          } else {
-            j = l.nbr[(size_t)me * K + k];
-            valid = in_game && (j >= 0);
-            j = max(j, 0);
-          }
-          const int o = eb + j;
-          if (c == 5) v = valid ? (float)l.types[j] : 0.0f;
-          else if (c == 6) v = valid ? (float)l.sig[o] : 0.0f;
-          else if (!valid || !in_game) v = 0.0f;
-          else if (c == 0) v = (float)(l.nx[o] - l.nx[me]);
-          else if (c == 1) v = (float)(l.ny[o] - l.ny[me]);
-          else if (c == 2) v = (float)((double)l.nsp[o] - (double)l.nsp[me]);
-          else if (c == 3) v = (float)((double)l.nac[o] - (double)l.nac[me]);
-          else v = (float)((double)l.ndir[o] - (double)l.ndir[me]);
+          j = ((const int *)l.cand)[(size_t)m * row_ints + k];
+          valid = in_game && (j >= 0);
+          j = max(j, 0);
         }
-        a.obs[obs_base + q] = v;
+        const int o = ebase + j;
+        float *row = obs_blk + (long)m * F;
+        const bool rel = valid && in_game;  // relative features only for agents in the game
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const double dv = l.feat[c * A + o] - l.feat[c * A + m];  // float64 difference, :560
+          row[c * W + k] = rel ? (float)dv : 0.0f;
+        }
+        row[5 * W + k] = valid ? (float)l.feat[5 * A + o] : 0.0f;
+        row[6 * W + k] = valid ? (float)l.feat[6 * A + o] : 0.0f;
+        // advance (m, i, k) by the block stride
+        k += sk;
+        int carry = (k >= W) ? 1 : 0;
+        k -= carry ? W : 0;
+        m += sm + carry;
+        i += si + carry;
+        i -= (i >= N) ? N : 0;
       }
-      if (!a.use_full_obs) {
-        const int per_env_k = N * K;
-        const long nb_base = (long)env0 * per_env_k;
-        for (int q = tid; q < envs_here * per_env_k; q += blockDim.x) a.nearest_ids[nb_base + q] = l.nbr[q];
+      // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
+      for (int m0 = tid; m0 < agents_here; m0 += T_)
+        obs_blk[(long)m0 * F + 7 * W] = (l.sig[m0] != 0) ? l.tfrac[m0 / N] : 0.0f;
+      if (!a.use_full_obs && K > 0) {
+        int *nb_blk = a.nearest_ids + (long)env0 * N * K;
+        int k2 = tid % K, m2 = tid / K;
+        const int sk2 = T_ % K, sm2 = T_ / K;
+        for (int q = tid; q < agents_here * K; q += T_) {
+          nb_blk[q] = ((const int *)l.cand)[(size_t)m2 * row_ints + k2];
+          k2 += sk2;
+          const int carry = (k2 >= K) ? 1 : 0;
+          k2 -= carry ? K : 0;
+          m2 += sm2 + carry;
+        }
       }
     }
 
@@ -279,12 +458,11 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
       if (sg) { rew += edge_pen; rew += a.step_rewards[ag]; }  // :655-658
       is_runner = (l.types[ag] == 0) && (sg != 0);              // member of self.runners
       if (is_runner) {
-        const float xi = l.x[li], yi = l.y[li];
         float best = __builtin_inff();
         int bt = -1;
         for (int t = 0; t < n_taggers; ++t) {  // ascending ids, first minimum wins :643-651
           const int j = l.tagger_ids[t];
-          const float dx = xi - l.x[el * N + j], dy = yi - l.y[el * N + j];
+          const float dx = my_x - l.x[el * N + j], dy = my_y - l.y[el * N + j];
           const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
           if (d < best) { best = d; bt = j; }
         }
@@ -297,17 +475,17 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
     }
     __syncthreads();
     if (active) {
-      if (tagged) rew += a.tag_penalty;                            // :664
+      if (tagged) rew += a.tag_penalty;                             // :664
       const int c = l.tagcnt[li];
-      for (int k = 0; k < c; ++k) rew += a.tag_reward;             // :665, one add per tag
+      for (int k = 0; k < c; ++k) rew += a.tag_reward;              // :665, one add per tag
       const bool still_runner = is_runner && !(tagged && a.runner_exits);
       if (l.tstep[el] == a.T && still_runner) rew += a.end_reward;  // :674-676
       a.rewards[gi] = rew;
-      if (tagged && a.runner_exits) a.sig_arr[gi] = 0;             // :669
+      if (tagged && a.runner_exits) a.sig_arr[gi] = 0;              // :669
       if (ag == 0) {
         const int nr = l.nrun[el];
         a.num_runners[env] = nr;
-        if (l.tstep[el] >= a.T || nr == 0) a.done[env] = 1;        // :880-883
+        if (l.tstep[el] >= a.T || nr == 0) a.done[env] = 1;         // :880-883
       }
     }
     __syncthreads();
@@ -327,7 +505,8 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
       int *nearest_neighbor_ids, float *rewards_arr, const float *step_rewards_arr,               \
       int *num_runners_arr, float kDistanceMarginForReward, float kTagRewardForTagger,            \
       float kTagPenaltyForRunner, float kEndOfGameRewardForRunner, int *done_arr,                 \
-      int *env_timestep_arr, int kNumAgents, int kEpisodeLength, int kNumEnvs
+      int *env_timestep_arr, int kNumAgents, int kEpisodeLength, int kNumEnvs,                    \
+      int kNumAccelerationActions, int kNumTurnActions
 
 #define WD_TC_PACK()                                                                              \
   TcArgs a;                                                                                       \
@@ -352,15 +531,16 @@ extern "C" {
 __global__ void HipTagContinuousStep(WD_TC_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
   WD_TC_PACK();
-  tc_step_impl<0>(a, tc_smem);
+  tc_step_impl<0>(a, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
-// register-resident top-K specialisations; the host picks the smallest KMAX >= K
-#define WD_TC_SPECIALISE(KM)                                           \
-  __global__ void HipTagContinuousStep_K##KM(WD_TC_PARAMS) {           \
+// register-resident top-K specialisations (blocks of <= 512 threads); the host picks the
+// smallest KMAX >= K and falls back to the generic entry for > 512 agents per replica
+#define WD_TC_SPECIALISE(KM)                                                \
+  __global__ void __launch_bounds__(512) HipTagContinuousStep_K##KM(WD_TC_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[]; \
-    WD_TC_PACK();                                                      \
-    tc_step_impl<KM>(a, tc_smem);                                      \
+    WD_TC_PACK();                                                           \
+    tc_step_impl<KM>(a, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }
 WD_TC_SPECIALISE(2)
 WD_TC_SPECIALISE(4)

@@ -255,6 +255,8 @@ class TagContinuous(CUDAEnvironmentContext):
         feed.add_data(name="max_speed", data=self.max_speed)
         feed.add_data(name="acceleration_actions", data=self.acceleration_actions)
         feed.add_data(name="turn_actions", data=self.turn_actions)
+        feed.add_data(name="num_acceleration_actions", data=len(self.acceleration_actions))
+        feed.add_data(name="num_turn_actions", data=len(self.turn_actions))
         feed.add_data(name="skill_levels", data=self.skill_levels)
         feed.add_data(name="use_full_observation", data=self.use_full_observation)
         feed.add_data(name="distance_margin_for_reward", data=self.distance_margin_for_reward)
@@ -280,11 +282,12 @@ class TagContinuous(CUDAEnvironmentContext):
         "nearest_neighbor_ids", _REWARDS, "step_rewards", "num_runners", "distance_margin_for_reward",
         "tag_reward_for_tagger", "tag_penalty_for_runner", "end_of_game_reward_for_runner", "_done_",
         "_timestep_", ("n_agents", "meta"), ("episode_length", "meta"), ("n_envs", "meta"),
+        "num_acceleration_actions", "num_turn_actions",
     ]
 
     def resolve_step_function_name(self, default_name):
         """Pick the register-resident top-K specialisation that covers K (partial obs only)."""
-        if self.use_full_observation:
+        if self.use_full_observation or self.num_agents > 512:
             return default_name
         for k in _K_SPECIALISATIONS:
             if k >= self.num_other_agents_observed:
@@ -292,9 +295,11 @@ class TagContinuous(CUDAEnvironmentContext):
         return default_name
 
     def lds_bytes(self, epb):
-        A = epb * self.num_agents
+        """dynamic LDS of HipTagContinuousStep for `epb` packed replicas (tc_carve in the kernel)"""
+        N = self.num_agents
+        A = epb * N
         K = 0 if self.use_full_observation else self.num_other_agents_observed
-        return 16 * A + 4 * A * 7 + 4 * 2 * self.num_agents + 4 * A * K + 4 * (2 * epb + 1) + 16
+        return 8 * 7 * A + 8 * A * (K + 1) + 4 * 4 * A + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 3 * epb + 16
 
     def step_launch(self):
         """(function, args, block, grid, shared_bytes) of one device tick."""

@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libwdhip.so")
-HSACO_PATH = os.path.join(_CSRC, "wd_kernels.hsaco")
+HSACO_PATH = os.environ.get("WD_HSACO", os.path.join(_CSRC, "wd_kernels.hsaco"))  # override: experiments only
 
 # every symbol include/wd_hip.h declares (tests assert the library exports them all)
 C_ABI_SYMBOLS = (
