@@ -116,18 +116,13 @@ def main():
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from warp_drive_amd import distributed as wdd
+
+    rank, local_rank, world = wdd.rank_info()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the HIP path"
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    wdd.init_process_group(backend="nccl", device_id=local_rank)  # RCCL; no-op for one rank
 
     from warp_drive_amd.env_wrapper import EnvWrapper
     from warp_drive_amd.envs.tag_continuous import TagContinuous
@@ -152,10 +147,7 @@ def main():
     def run(n):
         engine.run(n) if args.mode == "plan" else engine.run_graph(n, 10)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = wdd.barrier
 
     # hipGraph capture is not allowed on the legacy default stream: use a side stream there
     side = torch.cuda.Stream() if args.mode == "graph" else None
@@ -172,10 +164,7 @@ def main():
     run(steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = wdd.max_over_ranks(elapsed)
 
     kern_ms, kern_n = (engine.plan.read_timing() if args.mode == "plan" else (0.0, 0))
     if args.mode == "graph" or kern_n == 0:
@@ -235,9 +224,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "env_steps/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {err}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    wdd.shutdown()
 
 
 if __name__ == "__main__":

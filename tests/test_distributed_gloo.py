@@ -1,0 +1,85 @@
+"""world_size = 2 on CPU (gloo): the N > 1 path of bench.py / the rollout -- replica
+sharding with no data-path collective, per-rank seeds, barrier + max-over-ranks timing."""
+import json
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_envs, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from warp_drive_amd import distributed as wdd
+    from warp_drive_amd.envs.tag_gridworld import TagGridWorld
+
+    r, _, w = wdd.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    first, count = wdd.shard_replicas(total_envs, w, r)
+    # every rank steps its own replicas (host env here; the device path is identical per replica)
+    envs = [TagGridWorld(num_taggers=4, grid_length=6, episode_length=9) for _ in range(count)]
+    for e in envs:
+        e.reset()
+    xs = []
+    for t in range(12):
+        for i, e in enumerate(envs):
+            rng = np.random.RandomState(1000 * (first + i) + t)  # action stream keyed by GLOBAL replica id
+            _, _, done, _ = e.step({a: int(rng.randint(5)) for a in range(5)})
+            if done["__all__"]:
+                e.reset()
+        xs.append(np.stack([e.global_state["loc_x"][e.timestep] for e in envs]))
+    wdd.barrier()
+    elapsed = 1.0 + rank  # rank 1 is "slower": the job's time must be the max
+    agg = wdd.aggregate_throughput(count * 12, elapsed)
+    np.save(os.path.join(out_dir, f"x_{rank}.npy"), np.stack(xs))
+    with open(os.path.join(out_dir, f"r_{rank}.json"), "w") as f:
+        json.dump({"first": first, "count": count, "agg": agg, "seed": wdd.rank_seed(274880, r),
+                   "max_t": wdd.max_over_ranks(elapsed)}, f)
+    wdd.shutdown()
+
+
+def test_two_rank_sharding(tmp_path):
+    total, world = 7, 2  # ragged on purpose
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    recs = [json.load(open(tmp_path / f"r_{r}.json")) for r in range(world)]
+    assert [(r["first"], r["count"]) for r in recs] == [(0, 4), (4, 3)]
+    assert [r["seed"] for r in recs] == [274880, 274881]
+    for r in recs:
+        assert r["max_t"] == 2.0 and abs(r["agg"] - 7 * 12 / 2.0) < 1e-9
+    # sharded result == unsharded result: replicas are independent, no collective needed
+    from warp_drive_amd.envs.tag_gridworld import TagGridWorld
+
+    envs = [TagGridWorld(num_taggers=4, grid_length=6, episode_length=9) for _ in range(total)]
+    for e in envs:
+        e.reset()
+    ref = []
+    for t in range(12):
+        for i, e in enumerate(envs):
+            rng = np.random.RandomState(1000 * i + t)
+            _, _, done, _ = e.step({a: int(rng.randint(5)) for a in range(5)})
+            if done["__all__"]:
+                e.reset()
+        ref.append(np.stack([e.global_state["loc_x"][e.timestep] for e in envs]))
+    got = np.concatenate([np.load(tmp_path / f"x_{r}.npy") for r in range(world)], axis=1)
+    np.testing.assert_array_equal(got, np.stack(ref))
+
+
+def test_shard_replicas_covers_everything():
+    from warp_drive_amd.distributed import shard_replicas
+
+    for total in (1, 7, 2000, 16000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_replicas(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+    assert shard_replicas(16000, 8, 3) == (6000, 2000)

@@ -1,0 +1,81 @@
+"""Multi-GPU plumbing of the rollout path: one process per GPU, replicas sharded across
+ranks with NO data-path collective (replicas never interact; reference
+training/utils/device_child_process/process_group_torch.py:6-20 + trainer_base.py:249-252).
+
+backend "nccl" is RCCL on ROCm (8 x MI355X over xGMI); "gloo" runs the same code on CPU and
+is what the world_size-2 tests use.  The only collectives are a barrier and the reduction of
+per-rank wall times -- the gradient all-reduce belongs to the trainer (DDP)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def rank_info():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None, device_id=None):
+    rank, local_rank, world = rank_info()
+    if world == 1:
+        return rank, local_rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {}
+    if backend == "nccl" and device_id is not None:
+        kwargs["device_id"] = torch.device("cuda", device_id)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def shard_replicas(total_envs, world, rank):
+    """Contiguous block of replicas owned by `rank` (16000 -> 8 x 2000): (first, count)."""
+    base, extra = divmod(int(total_envs), int(world))
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def rank_seed(base_seed, rank):
+    """seed + device id, trainer_base.py:249-252"""
+    return int(base_seed) + int(rank)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds):
+    """MAX of a per-rank wall time (the slowest rank defines the job's time)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def aggregate_throughput(units_this_rank, seconds_this_rank):
+    """Whole-job throughput: all ranks' units / the slowest rank's time."""
+    return sum_over_ranks(units_this_rank) / max_over_ranks(seconds_this_rank)
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
