@@ -79,9 +79,20 @@ struct TcCand {
   int id;
 };
 
+// observation features of one agent after the move, as the reference computes them (:453-470):
+// x, y normalised in float64; speed / acceleration / direction normalised in float32 (widened
+// to float64 only for the neighbour difference); type and still_in_game packed in one word.
+// 48 bytes = three 16-byte slots, so a neighbour is fetched with two ds_read_b128.
+struct __attribute__((aligned(16))) TcFeat {
+  double nx, ny;
+  float nsp, nac, ndir;
+  int type_sig;  // bit 0: agent type (1 = tagger), bit 1: still_in_the_game before tagging
+  int pad_[2];
+};
+
 // LDS carve-up for `epb` packed replicas, A = epb * N agents (offsets multiples of 8).
 struct TcLds {
-  double *feat;      // [7][A] nx, ny, nspeed, nacc, ndir, type, still_in_game(before tagging)
+  TcFeat *feat;      // [A] observation features (see TcFeat)
   TcCand *cand;      // [A][K+1] phase-1 lists; afterwards the first K ints of a row = neighbour ids
   float *x, *y;      // [A] positions after the move (x = +BIG for agents out of the game)
   int *sig;          // [A] still_in_the_game before this tick's tagging
@@ -99,7 +110,7 @@ struct TcLds {
 __device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K) {
   TcLds l;
   const size_t A = (size_t)epb * N;
-  l.feat = (double *)p; p += 8 * 7 * A;
+  l.feat = (TcFeat *)p; p += sizeof(TcFeat) * A;
   l.cand = (TcCand *)p; p += 8 * A * (K + 1);
   l.x = (float *)p; p += 4 * A;
   l.y = (float *)p; p += 4 * A;
@@ -213,30 +224,89 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
   for (int k = 1; k <= KMAX; ++k) c_less += (k <= K && B[k] < T2lo) ? 1 : 0;
   const int need_tie = K - c_less;
 
-  // B. collect the selected candidates in id order.  Branch-free: every candidate is written to
-  //    the next free slot and the slot only advances when it was selected (a row has K+1 slots,
-  //    so the write after the K-th selection stays inside the row).
-  int cnt = 0, tie_taken = 0;
-  for (int j = 0; j < N; ++j) {
-    const float dx = xi - cx[j], dy = yi - cy[j];
-    const float d2 = dx * dx + dy * dy;
-    const bool other = (j != ag);
-    const bool less = other && (d2 < T2lo);
-    const bool tie = other && !less && (d2 <= T2hi) && (tie_taken < need_tie);
-    mine[cnt] = TcCand{d2, j};
-    cnt += (less || tie) ? 1 : 0;
-    tie_taken += tie ? 1 : 0;
-  }
-  if (WD_TC_ABLATE & 8) return;
-
-  // C. order by (distance, id): 64-bit keys (float bits of sqrt(d2) << 32 | id)
   unsigned long long key[KMAX];
+  if (N <= 128) {
+    // B. second pass: two 128-bit per-lane masks, "below the range" and "inside or below the
+    //    range".  Each candidate costs a squared distance, two compares and two
+    //    shift-in-the-carry adds (m = 2m + bit); no LDS traffic, no data-dependent addressing.
+    //    Candidate b of word w lands on bit (nb-1-b): undone with one bit-reverse per word.
+    unsigned below[4] = {0u, 0u, 0u, 0u}, upto[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const bool have = k < cnt;
-    const TcCand c = mine[have ? k : 0];
-    const unsigned long long sbits = have ? (unsigned long long)__float_as_uint(sqrtf(c.d2)) : 0x7f800000ull;
-    key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? c.id : 0xffff);
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int nb = min(32, N - j0);
+        unsigned mb = 0u, mu = 0u;
+        for (int b = 0; b < nb; ++b) {
+          const float dx = xi - cx[j0 + b], dy = yi - cy[j0 + b];
+          const float d2 = dx * dx + dy * dy;
+          mb = mb + mb + ((d2 < T2lo) ? 1u : 0u);
+          mu = mu + mu + ((d2 <= T2hi) ? 1u : 0u);
+        }
+        below[w] = __brev(mb) >> (32 - nb);
+        upto[w] = __brev(mu) >> (32 - nb);
+      }
+    }
+    // selected = below | first `need_tie` members (ascending id) of the range; never self
+    unsigned sel[4];
+    int quota = need_tie;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
+      const unsigned lo = below[w] & ~self_bit;
+      unsigned tie = upto[w] & ~below[w] & ~self_bit;
+      // keep the lowest `quota` set bits of tie (ties are rare: the loop almost never runs)
+      const int have_t = __popc(tie);
+      if (have_t > quota) {
+        unsigned kept = 0u;
+        for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
+        tie = kept;
+      }
+      quota -= min(have_t, quota);
+      sel[w] = lo | tie;
+    }
+    if (WD_TC_ABLATE & 8) { ((unsigned *)mine)[0] = sel[0] ^ sel[1] ^ sel[2] ^ sel[3]; return; }
+    // C. peel the (at most K) ids off the mask in ascending order, rebuild their distances
+    //    and form 64-bit keys (float bits of sqrt(d2) << 32 | id)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int which = sel[0] ? 0 : sel[1] ? 1 : sel[2] ? 2 : sel[3] ? 3 : 4;
+      const unsigned cur = sel[0] ? sel[0] : sel[1] ? sel[1] : sel[2] ? sel[2] : sel[3];
+      const bool have = which < 4;
+      const int j = have ? which * 32 + (__ffs(cur) - 1) : ag;
+      const unsigned cleared = cur & (cur - 1u);
+      sel[0] = (which == 0) ? cleared : sel[0];
+      sel[1] = (which == 1) ? cleared : sel[1];
+      sel[2] = (which == 2) ? cleared : sel[2];
+      sel[3] = (which == 3) ? cleared : sel[3];
+      const float dx = xi - cx[j], dy = yi - cy[j];
+      const unsigned long long sbits =
+          have ? (unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000ull;
+      key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? j : 0xffff);
+    }
+  } else {
+    // B'. more than 128 agents: same selection, collected in a (K+1)-slot LDS row.  Branch-free:
+    //     every candidate is written to the next free slot and the slot only advances when it
+    //     was selected (the write after the K-th selection stays inside the row).
+    int cnt = 0, tie_taken = 0;
+    for (int j = 0; j < N; ++j) {
+      const float dx = xi - cx[j], dy = yi - cy[j];
+      const float d2 = dx * dx + dy * dy;
+      const bool other = (j != ag);
+      const bool less = other && (d2 < T2lo);
+      const bool tie = other && !less && (d2 <= T2hi) && (tie_taken < need_tie);
+      mine[cnt] = TcCand{d2, j};
+      cnt += (less || tie) ? 1 : 0;
+      tie_taken += tie ? 1 : 0;
+    }
+    if (WD_TC_ABLATE & 8) return;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const bool have = k < cnt;
+      const TcCand c = mine[have ? k : 0];
+      const unsigned long long sbits = have ? (unsigned long long)__float_as_uint(sqrtf(c.d2)) : 0x7f800000ull;
+      key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? c.id : 0xffff);
+    }
   }
   tc_sort_network<KMAX>(key);
   int *out = (int *)mine;
@@ -357,13 +427,15 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
       // consumer (taggers are never out of the game) reads real positions
       l.x[li] = sg ? px : WD_BIG;
       l.y[li] = py;
-      l.feat[0 * A + li] = (double)px / diag;            // :462 (float64 division)
-      l.feat[1 * A + li] = (double)py / diag;
-      l.feat[2 * A + li] = (double)(v / sp_div);         // float32 division, then widened
-      l.feat[3 * A + li] = (double)(acc / sp_div);
-      l.feat[4 * A + li] = (double)(dir / two_pi);
-      l.feat[5 * A + li] = (double)l.types[ag];
-      l.feat[6 * A + li] = (double)sg;
+      TcFeat ft;
+      ft.nx = (double)px / diag;    // :462 (float64 division)
+      ft.ny = (double)py / diag;
+      ft.nsp = v / sp_div;          // float32 division (:456-458)
+      ft.nac = acc / sp_div;
+      ft.ndir = dir / two_pi;
+      ft.type_sig = (l.types[ag] & 1) | (sg ? 2 : 0);
+      ft.pad_[0] = 0; ft.pad_[1] = 0;
+      l.feat[li] = ft;
       l.sig[li] = sg;
       l.tagcnt[li] = 0;
       if (ag == 0) {
@@ -418,13 +490,35 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
         const int o = ebase + j;
         float *row = obs_blk + (long)m * F;
         const bool rel = valid && in_game;  // relative features only for agents in the game
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          const double dv = l.feat[c * A + o] - l.feat[c * A + m];  // float64 difference, :560
-          row[c * W + k] = rel ? (float)dv : 0.0f;
+        TcFeat nb, me;
+        if (WD_TC_ABLATE & 64) {  // timing experiment: no LDS feature reads
+          nb.nx = 1.0 + o; nb.ny = 2.0; nb.nsp = 0.5f; nb.nac = 0.25f; nb.ndir = 0.125f; nb.type_sig = o;
+          me = nb; me.nx = 0.5;
+        } else {
+          nb = l.feat[o];
+          me = l.feat[m];
         }
-        row[5 * W + k] = valid ? (float)l.feat[5 * A + o] : 0.0f;
-        row[6 * W + k] = valid ? (float)l.feat[6 * A + o] : 0.0f;
+        float vals[7];
+        // float64 differences (:560), narrowed to float32 like the reference's device push
+        vals[0] = rel ? (float)(nb.nx - me.nx) : 0.0f;
+        vals[1] = rel ? (float)(nb.ny - me.ny) : 0.0f;
+        // speed / acc / dir: the reference widens float32 values and subtracts in float64; for
+        // float32 operands that rounds to exactly the float32 difference (53 >= 2*24+2 bits:
+        // double rounding is innocuous), so no float64 arithmetic is needed here
+        vals[2] = rel ? (nb.nsp - me.nsp) : 0.0f;
+        vals[3] = rel ? (nb.nac - me.nac) : 0.0f;
+        vals[4] = rel ? (nb.ndir - me.ndir) : 0.0f;
+        vals[5] = valid ? (float)(nb.type_sig & 1) : 0.0f;
+        vals[6] = valid ? (float)((nb.type_sig >> 1) & 1) : 0.0f;
+        if (WD_TC_ABLATE & 16) {  // timing experiment: keep the math, drop the stores
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) acc += vals[c];
+          if (acc == 123.456f) row[0] = acc;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) row[c * W + k] = vals[c];
+        }
         // advance (m, i, k) by the block stride
         k += sk;
         int carry = (k >= W) ? 1 : 0;
@@ -434,9 +528,10 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
         i -= (i >= N) ? N : 0;
       }
       // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
+      if (!(WD_TC_ABLATE & 32))
       for (int m0 = tid; m0 < agents_here; m0 += T_)
         obs_blk[(long)m0 * F + 7 * W] = (l.sig[m0] != 0) ? l.tfrac[m0 / N] : 0.0f;
-      if (!a.use_full_obs && K > 0) {
+      if (!a.use_full_obs && K > 0 && !(WD_TC_ABLATE & 32)) {
         int *nb_blk = a.nearest_ids + (long)env0 * N * K;
         int k2 = tid % K, m2 = tid / K;
         const int sk2 = T_ % K, sm2 = T_ / K;
