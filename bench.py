@@ -114,6 +114,8 @@ def main():
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
+    ap.add_argument("--unfused", action="store_true",
+                    help="tick = 4 launches (sample x2, step, fused reset) instead of the single tick kernel")
     args = ap.parse_args()
 
     from warp_drive_amd import distributed as wdd
@@ -138,7 +140,7 @@ def main():
     sampler.init_random(seed=cfg["seed"] + rank)  # seed + device id, trainer_base.py:249-252
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
-    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset)
+    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused)
     steps, warmup = args.steps, args.warmup
     if args.mode == "graph":
         steps = max(10, steps // 10 * 10)
@@ -177,7 +179,11 @@ def main():
 
     if rank == 0:
         N, K = w.n_agents, cfg["num_other_agents_observed"]
-        bytes_per_launch = step_algorithmic_bytes(N, K, cfg["use_full_observation"]) * E
+        bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
+        if engine.fused:
+            # the tick kernel also reads both heads' probabilities and reads+writes the RNG epoch
+            bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
+        bytes_per_launch = bytes_per_env_step * E
         kern_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic = None
@@ -206,7 +212,8 @@ def main():
                 "workload": "BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
                             f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}, "
                             f"num_envs={E} per GPU; tick = sample_actions x2 heads + step"
-                            f"{'' if args.no_reset else ' + fused reset'}",
+                            f"{'' if args.no_reset else ' + reset of finished replicas'}"
+                            f"{' (one fused launch)' if engine.fused else ''}",
                 "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode,
                 "kernels_per_tick": len(engine.entry_names), "parallelism": f"env-replica sharding x{world}",
             },

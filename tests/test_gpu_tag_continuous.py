@@ -196,3 +196,65 @@ def test_bench_full_size_properties():
     np.testing.assert_array_equal(pull(w, "loc_x")[: 8 * G: G], orc.loc_x)
     np.testing.assert_array_equal(pull(w, REW)[: 8 * G: G], orc.rewards)
     np.testing.assert_array_equal(pull(w, OBS)[: 8 * G: G], orc.obs.astype(np.float32))
+
+
+@pytest.mark.parametrize("full_obs", [False, True])
+def test_fused_tick_kernel(full_obs):
+    """HipTagContinuousTick: sampling + step + in-kernel reset in ONE launch.  The actions it
+    sampled are pulled back and replayed through the oracle; finished replicas must already
+    be reset when the launch returns while `_done_` still reports them for the trainer."""
+    import torch
+    from tests.hip_harness import OBS, REW, make_wrapper, pull, require_gpu
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.managers.function_manager import HIPSampler
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+    from warp_drive_amd.env_wrapper import EnvWrapper
+
+    require_gpu()
+    cfg = dict(num_taggers=4, num_runners=30, grid_length=6.0, episode_length=11, seed=5, max_speed=0.6,
+               max_acceleration=0.3, min_acceleration=-0.3, num_acceleration_levels=6, num_turn_levels=8,
+               use_full_observation=full_obs, num_other_agents_observed=6, tagging_distance=0.12,
+               edge_hit_penalty=-0.2, step_reward_for_runner=0.01, runner_exits_game_after_tagged=True)
+    E = 23
+    w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
+    w.reset_all_envs()
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=11)
+    create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                      push_data_batch_placeholders=False)
+    rng = np.random.RandomState(0)
+    N = w.n_agents
+    probs = [torch.from_numpy(rng.dirichlet(np.ones(a), size=(E, N)).astype(np.float32)).cuda() for a in (7, 9)]
+    engine = RolloutEngine(w, sampler, probabilities=probs)
+    assert engine.fused and engine.step_kernel_name.startswith("HipTagContinuousTick")
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    stats = {"near_tie_rows": 0, "rows": 0}
+    counts = [np.zeros(7), np.zeros(9)]
+    finished_total = 0
+    for t in range(40):
+        engine.run(1)
+        torch.cuda.synchronize()
+        a = pull(w, "sampled_actions")
+        assert a[..., 0].max() < 7 and a[..., 1].max() < 9 and a.min() >= 0
+        counts[0] += np.bincount(a[..., 0].reshape(-1), minlength=7)
+        counts[1] += np.bincount(a[..., 1].reshape(-1), minlength=9)
+        orc.step(a)
+        np.testing.assert_array_equal(pull(w, REW), orc.rewards, err_msg=f"rewards t={t}")
+        np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")  # still set
+        fin = orc.done > 0
+        finished_total += int(fin.sum())
+        obs_before_reset = orc.obs.astype(np.float32).copy()
+        orc.reset_done_envs()
+        for name, attr in STATE:
+            np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
+        obs_dev = pull(w, OBS)
+        np.testing.assert_array_equal(obs_dev[fin], orc.obs.astype(np.float32)[fin])      # reset observation
+        live = ~fin
+        if not np.array_equal(obs_dev[live], obs_before_reset[live]):
+            assert not full_obs
+            stats["near_tie_rows"] += int((obs_dev[live] != obs_before_reset[live]).any(axis=2).sum())
+    assert finished_total >= 2 * E and stats["near_tie_rows"] <= 1
+    for c, p in zip(counts, probs):
+        expected = p.cpu().numpy().reshape(-1, c.size).sum(0) * 40
+        assert np.abs(c - expected).max() < 6 * np.sqrt(expected.max())

@@ -79,6 +79,24 @@ struct TcCand {
   int id;
 };
 
+// extra inputs of the fused rollout tick (sample both action heads -> step -> reset finished
+// replicas, ONE launch; see HipTagContinuousTick below)
+struct TcResetEntry {  // same layout as wd_reset_entry in wd_core.hip
+  uint32_t *data;
+  const uint32_t *ref;
+  int row_elems;
+  int pad_;
+};
+struct TcFuse {
+  uint32_t *rng_state;             // Philox epoch counters (WD_RNG_HEADER + one word per agent row)
+  const float *probs_acc;          // [E, N, n_acc]  policy output, head 0
+  const float *probs_turn;         // [E, N, n_turn] policy output, head 1
+  int *actions_out;                // [E, N, 2] sampled_actions
+  const TcResetEntry *reset_table; // arrays registered with save_copy_and_apply_at_reset
+  int n_reset_arrays;
+  int stream_tag;
+};
+
 // observation features of one agent after the move, as the reference computes them (:453-470):
 // x, y normalised in float64; speed / acceleration / direction normalised in float32 (widened
 // to float64 only for the neighbour difference); type and still_in_game packed in one word.
@@ -103,15 +121,21 @@ struct TcLds {
   int *wave_cnt;     // [16] taggers per wavefront (rank computation)
   int *tstep, *nrun; // [epb]
   float *tfrac;      // [epb] float(t) / episode_length
+  int *doneflag;     // [epb] replica finished on this tick (fused tick only)
 };
 
 #define WD_TC_TAB 64  // capacity of the LDS copies of the action tables
 
-__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K) {
+__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K, size_t min_list_bytes) {
   TcLds l;
   const size_t A = (size_t)epb * N;
   l.feat = (TcFeat *)p; p += sizeof(TcFeat) * A;
-  l.cand = (TcCand *)p; p += 8 * A * (K + 1);
+  {
+    // the list region doubles as the probability slab of the fused tick
+    size_t bytes = 8 * A * (K + 1);
+    bytes = bytes > min_list_bytes ? bytes : min_list_bytes;
+    l.cand = (TcCand *)p; p += (bytes + 15) & ~(size_t)15;
+  }
   l.x = (float *)p; p += 4 * A;
   l.y = (float *)p; p += 4 * A;
   l.sig = (int *)p; p += 4 * A;
@@ -123,7 +147,8 @@ __device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int 
   l.wave_cnt = (int *)p; p += 4 * 16;
   l.tstep = (int *)p; p += 4 * epb;
   l.nrun = (int *)p; p += 4 * epb;
-  l.tfrac = (float *)p;
+  l.tfrac = (float *)p; p += 4 * epb;
+  l.doneflag = (int *)p;
   return l;
 }
 
@@ -343,14 +368,14 @@ __device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, i
   }
 }
 
-template <int KMAX>
-__device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *smem, int n_acc, int n_turn) {
+template <int KMAX, bool FUSED>
+__device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
+                                             int n_turn) {
   const int N = a.N, K = a.use_full_obs ? 0 : a.K;
   const int W = a.use_full_obs ? (N - 1) : K;  // columns per feature
   const int F = 7 * W + 1;
   const int epb = max(1, (int)blockDim.x / N);
-  const int A = epb * N;
-  const TcLds l = tc_carve(smem, epb, N, K);
+  const TcLds l = tc_carve(smem, epb, N, K, FUSED ? (size_t)4 * epb * N * max(n_acc, n_turn) : 0);
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const int row_ints = 2 * (K + 1);                    // ints per agent row of the id list
@@ -393,12 +418,52 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
     const int gi = env * N + ag;  // index into [E, N] arrays
     const int li = el * N + ag;   // index into LDS arrays
     float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
+    int2 sampled = make_int2(0, 0);
+
+    // ------------------------------------------- fused tick: sample both action heads
+    // (replaces two sample_actions launches, random.cu:51-85).  The block's rows of a head are
+    // one contiguous slab: coalesced load into LDS (the phase-1 list region is free now), each
+    // thread scans its own row; one Philox call serves both heads.
+    if (FUSED) {
+      if (active && ag == 0 && a.done[env] != 0) a.done[env] = 0;  // finished (and reset) last tick
+      const int rows_here = min(epb, a.E - env0) * N;
+      float *slab = (float *)l.cand;
+      wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
+      if (active) {
+        const uint32_t epoch = fz.rng_state[WD_RNG_HEADER + gi];
+        fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
+        rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
+                               fz.rng_state[1]);
+      }
+#pragma unroll
+      for (int head = 0; head < 2; ++head) {
+        const int na = head == 0 ? n_acc : n_turn;
+        const float *src = (head == 0 ? fz.probs_acc : fz.probs_turn) + (long)env0 * N * na;
+        __syncthreads();  // previous users of the slab region are done
+        for (int i = tid; i < rows_here * na; i += T_) slab[i] = src[i];
+        __syncthreads();
+        if (active) {
+          const float u = wd_u01_open_closed(head == 0 ? rnd.x : rnd.y);
+          const float *pr = slab + (size_t)li * na;
+          float cum = 0.0f;
+          int cnt = 0;
+          for (int i = 0; i < na; ++i) {
+            cum = (i == 0) ? pr[0] : cum + pr[i];
+            cnt += (cum < u) ? 1 : 0;
+          }
+          const int idx = min(cnt, na - 1);
+          if (head == 0) sampled.x = idx; else sampled.y = idx;
+        }
+      }
+      if (active) ((int2 *)fz.actions_out)[gi] = sampled;
+      __syncthreads();  // the slab region becomes the phase-1 list region again
+    }
 
     // ------------------------------------------------------------ phase 0: move
     if (active) {
       const int sg = a.sig_arr[gi];
       const float s = (float)sg;
-      const int2 act = ((const int2 *)a.actions)[gi];
+      const int2 act = FUSED ? sampled : ((const int2 *)a.actions)[gi];
       const float d_acc = tab_in_lds ? l.acc_tab[act.x] : a.acc_actions[act.x];
       const float d_turn = tab_in_lds ? l.turn_tab[act.y] : a.turn_actions[act.y];
       const float dir = wd_np_remainderf(a.direction[gi] + d_turn, two_pi) * s;  // :355-357
@@ -580,10 +645,29 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, unsigned char *sme
       if (ag == 0) {
         const int nr = l.nrun[el];
         a.num_runners[env] = nr;
-        if (l.tstep[el] >= a.T || nr == 0) a.done[env] = 1;         // :880-883
+        const bool fin = (l.tstep[el] >= a.T || nr == 0);           // :880-883
+        if (fin) a.done[env] = 1;
+        if (FUSED) l.doneflag[el] = fin ? 1 : 0;
       }
     }
     __syncthreads();
+    // ------------------------------------------- fused tick: reset finished replicas in place
+    // (reset.cu:9-75 for every registered array).  `_done_` stays 1 so the trainer can read
+    // which replicas finished on this tick; the next tick clears it.  All writes of this block
+    // to these rows happened before the barrier above.
+    if (FUSED) {
+      const int envs_here = min(epb, a.E - env0);
+      for (int e = 0; e < envs_here; ++e) {
+        if (l.doneflag[e] == 0) continue;  // block-uniform
+        for (int r = 0; r < fz.n_reset_arrays; ++r) {
+          const TcResetEntry ent = fz.reset_table[r];
+          const long base = (long)(env0 + e) * ent.row_elems;
+          for (int i = tid; i < ent.row_elems; i += T_) ent.data[base + i] = ent.ref[base + i];
+        }
+        if (tid == 0) a.timestep[env0 + e] = 0;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -626,16 +710,42 @@ extern "C" {
 __global__ void HipTagContinuousStep(WD_TC_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
   WD_TC_PACK();
-  tc_step_impl<0>(a, tc_smem, kNumAccelerationActions, kNumTurnActions);
+  tc_step_impl<0, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);
+}
+
+// Fused rollout tick: sample both action heads + step + reset finished replicas in ONE launch
+// (the reference needs 2 sampler launches, the step, and 13 reset launches per tick,
+// trainer_base.py:392-426).  Same arguments as the step plus the sampler / reset inputs.
+#define WD_TC_FUSE_PARAMS                                                                      \
+  , uint32_t *rng_state, const float *probs_acc, const float *probs_turn, const void *reset_table, \
+      int n_reset_arrays, int stream_tag
+#define WD_TC_FUSE_PACK()                                                                      \
+  TcFuse fz;                                                                                   \
+  fz.rng_state = rng_state; fz.probs_acc = probs_acc; fz.probs_turn = probs_turn;              \
+  fz.actions_out = const_cast<int *>(action_indices_arr);                                      \
+  fz.reset_table = (const TcResetEntry *)reset_table; fz.n_reset_arrays = n_reset_arrays;      \
+  fz.stream_tag = stream_tag;
+
+__global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  WD_TC_PACK();
+  WD_TC_FUSE_PACK();
+  tc_step_impl<0, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
 // register-resident top-K specialisations (blocks of <= 512 threads); the host picks the
 // smallest KMAX >= K and falls back to the generic entry for > 512 agents per replica
-#define WD_TC_SPECIALISE(KM)                                                \
-  __global__ void __launch_bounds__(512) HipTagContinuousStep_K##KM(WD_TC_PARAMS) { \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[]; \
-    WD_TC_PACK();                                                           \
-    tc_step_impl<KM>(a, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+#define WD_TC_SPECIALISE(KM)                                                                   \
+  __global__ void __launch_bounds__(512) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    tc_step_impl<KM, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
+  }                                                                                            \
+  __global__ void __launch_bounds__(512) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    WD_TC_FUSE_PACK();                                                                         \
+    tc_step_impl<KM, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);          \
   }
 WD_TC_SPECIALISE(2)
 WD_TC_SPECIALISE(4)

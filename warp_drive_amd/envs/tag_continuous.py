@@ -15,6 +15,7 @@ the two differ by one ulp for ~0.07 % of inputs and only matter for exact near-t
 The device kernel squares the same way, so host and device agree with each other.
 """
 import copy
+import os
 
 import numpy as np
 
@@ -294,24 +295,49 @@ class TagContinuous(CUDAEnvironmentContext):
                 return f"{default_name}_K{k}"
         return default_name
 
-    def lds_bytes(self, epb):
-        """dynamic LDS of HipTagContinuousStep for `epb` packed replicas (tc_carve in the kernel)"""
+    def lds_bytes(self, epb, fused=False):
+        """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve in the kernel)"""
         N = self.num_agents
         A = epb * N
         K = 0 if self.use_full_observation else self.num_other_agents_observed
-        return 48 * A + 8 * A * (K + 1) + 4 * 4 * A + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 3 * epb + 16
+        lists = 8 * A * (K + 1)
+        if fused:  # the list region doubles as the probability slab
+            lists = max(lists, 4 * A * max(len(self.acceleration_actions), len(self.turn_actions)))
+        lists = (lists + 15) // 16 * 16
+        return 48 * A + lists + 4 * 4 * A + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16
 
-    def step_launch(self):
-        """(function, args, block, grid, shared_bytes) of one device tick."""
-        import os
-
+    def _geometry(self):
         # 256 threads = one wavefront per SIMD: measured 1.3x faster than the denser 320-thread
         # packing (3 replicas) whose 5 wavefronts load the 4 SIMDs unevenly
-        max_threads = int(os.environ.get("WD_TC_MAX_THREADS", "256"))
+        max_threads = int(os.environ.get("WD_TC_MAX_THREADS", "256"))  # override: geometry experiments
         epb, block, grid = self.cuda_function_manager.packed_geometry(self.num_agents, max_threads=max_threads)
         if "WD_TC_GRID" in os.environ:  # experiments: fewer blocks, each looping over replica groups
             grid = (min(grid[0], int(os.environ["WD_TC_GRID"])), 1)
+        return epb, block, grid
+
+    def step_launch(self):
+        """(function, args, block, grid, shared_bytes) of one device tick."""
+        epb, block, grid = self._geometry()
         return self.cuda_step, self.cuda_step_function_feed(self._STEP_ARGS), block, grid, self.lds_bytes(epb)
+
+    def tick_launch(self, sampler, probabilities, resetter):
+        """Fused rollout tick: sample both action heads + step + reset finished replicas in ONE
+        launch (HipTagContinuousTick[_K<k>]).  probabilities = [acceleration, turn] float32 CUDA
+        tensors [E, N, n_actions].  `_done_` stays set for replicas that finished on the tick
+        (already reset); the next tick clears it."""
+        from warp_drive_amd.managers.function_manager import _stream_tag
+
+        fm, dm = self.cuda_function_manager, self.cuda_data_manager
+        name = self.cuda_step.name.replace("Step", "Tick")
+        fm.initialize_functions([name])
+        fn = fm.get_function(name)
+        _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
+        table, n_arrays = reset_args[0], reset_args[1]
+        assert len(probabilities) == 2
+        epb, block, grid = self._geometry()
+        args = list(self.cuda_step_function_feed(self._STEP_ARGS)) + [
+            sampler.rng_state, probabilities[0], probabilities[1], table, n_arrays, _stream_tag("tick")]
+        return fn, args, block, grid, self.lds_bytes(epb, fused=True)
 
     # ------------------------------------------------------------------------------ step
     def step(self, actions=None):

@@ -26,7 +26,7 @@ _ACTIONS = Constants.ACTIONS
 
 
 class RolloutEngine:
-    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True):
+    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform."""
         assert env_wrapper.env_backend == "hip"
@@ -53,6 +53,17 @@ class RolloutEngine:
         actions = dm.device_data(_ACTIONS)  # [E, N, H] int32 (H = 1 for Discrete)
         H = len(head_sizes)
         self.entry_names = []
+        self._graph_ticks = 0
+        self.fused = bool(fused and reset_done and hasattr(env_wrapper.env, "tick_launch") and H == 2)
+        if self.fused:
+            # whole tick = ONE launch: sampling, step and reset fused in the env's tick kernel
+            fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
+                                                                        env_wrapper.env_resetter)
+            self.plan.add(fn, args, block, grid, shared)
+            self.step_entry = 0
+            self.step_kernel_name = fn.name
+            self.entry_names.append(fn.name)
+            return
         for k, (p, a) in enumerate(zip(probabilities, head_sizes)):
             fn, args, block, grid, shared = sampler.categorical_launch(
                 p, actions, E * N, a, False, _stream_tag(f"{_ACTIONS}_{k}"), out_stride=H, out_offset=k)
@@ -67,7 +78,6 @@ class RolloutEngine:
             fn, args, block, grid = env_wrapper.env_resetter.fused_launch(dm, np.int32(0), 1)
             self.plan.add(fn, args, block, grid, 0)
             self.entry_names.append(fn.name)
-        self._graph_ticks = 0
 
     def run(self, ticks, stream=None):
         """Enqueue `ticks` rollout ticks (asynchronous)."""
