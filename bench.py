@@ -114,6 +114,9 @@ def main():
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="replica groups on separate HIP streams (fused tick only): overlaps the memory-bound "
+                         "phases of one group with the neighbour search of another")
     ap.add_argument("--unfused", action="store_true",
                     help="tick = 4 launches (sample x2, step, fused reset) instead of the single tick kernel")
     args = ap.parse_args()
@@ -140,7 +143,8 @@ def main():
     sampler.init_random(seed=cfg["seed"] + rank)  # seed + device id, trainer_base.py:249-252
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
-    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused)
+    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused,
+                           n_groups=args.groups)
     steps, warmup = args.steps, args.warmup
     if args.mode == "graph":
         steps = max(10, steps // 10 * 10)
@@ -214,7 +218,7 @@ def main():
                             f"num_envs={E} per GPU; tick = sample_actions x2 heads + step"
                             f"{'' if args.no_reset else ' + reset of finished replicas'}"
                             f"{' (one fused launch)' if engine.fused else ''}",
-                "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode,
+                "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode, "replica_groups": args.groups,
                 "kernels_per_tick": len(engine.entry_names), "parallelism": f"env-replica sharding x{world}",
             },
             "roofline": {

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Phase timing of HipTagContinuousTick with s_memtime stamps (WD_TC_PROFILE build).
+Run on the GPU box:  python scripts/phase_profile.py"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "build", "prof")
+os.makedirs(out, exist_ok=True)
+hsaco = os.path.join(out, "wd_kernels_prof.hsaco")
+subprocess.run(["hipcc", "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
+                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-DWD_TC_PROFILE",
+                os.path.join(ROOT, "warp_drive_amd/csrc/kernels/wd_kernels.hip"), "-o", hsaco], check=True)
+os.environ["WD_HSACO"] = hsaco
+os.environ["WD_TC_PROFILE"] = "1"
+import numpy as np
+import torch
+
+import bench
+from warp_drive_amd.env_wrapper import EnvWrapper
+from warp_drive_amd.envs.tag_continuous import TagContinuous
+from warp_drive_amd.managers.function_manager import HIPSampler
+from warp_drive_amd.rollout import RolloutEngine
+from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+E = 2000
+w = EnvWrapper(env_obj=TagContinuous(**bench.BENCH_CFG), num_envs=E, env_backend="hip")
+w.reset_all_envs()
+sampler = HIPSampler(w.cuda_function_manager)
+sampler.init_random(seed=1)
+create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                  push_data_batch_placeholders=False)
+for fused in (True, False):
+    engine = RolloutEngine(w, sampler, fused=fused)
+    engine.run(50)
+    torch.cuda.synchronize()
+    raw = w.cuda_data_manager.pull_data_from_device("neighbor_distances").view(np.uint64).reshape(-1, 16)
+    n_blocks = 1000
+    st = raw[:n_blocks].astype(np.int64)
+    names = {0: "start", 1: "prologue done", 2: "sampling done", 3: "move (P0) done", 4: "knn A done",
+             5: "knn B done", 6: "knn C done", 7: "barrier after knn", 9: "obs gather issued", 10: "rewards done"}
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10]
+    print(f"--- {'fused tick' if fused else 'step only'}: mean cycles (s_memtime, 100 MHz ticks?) per phase, wave 0 of each block")
+    prev = None
+    for k in order:
+        if prev is not None:
+            d = st[:, k] - st[:, prev]
+            print(f"{names[k]:<22} mean={d.mean():10.0f} p10={np.percentile(d,10):9.0f} p90={np.percentile(d,90):9.0f}")
+        prev = k
+    tot = st[:, 10] - st[:, 0]
+    print(f"{'total':<22} mean={tot.mean():10.0f}   spread of block start = {st[:,0].max()-st[:,0].min()}")

@@ -48,6 +48,13 @@
 #ifndef WD_TC_ABLATE
 #define WD_TC_ABLATE 0
 #endif
+// -DWD_TC_PROFILE: thread 0 of every block stores s_memtime stamps at the phase boundaries into
+// the (otherwise unused) neighbor_distances array, 16 x uint64 per block (scripts/phase_profile.py).
+#ifdef WD_TC_PROFILE
+#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && a.prof) a.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WD_TC_STAMP(slot) do { } while (0)
+#endif
 
 namespace {
 
@@ -72,6 +79,8 @@ struct TcArgs {
   float margin, tag_reward, tag_penalty, end_reward;
   int *done, *timestep;
   int N, T, E;
+  int env_begin;  // first replica of this launch (a launch covers replicas [env_begin, E))
+  unsigned long long *prof;  // phase time stamps (profiling builds only)
 };
 
 struct TcCand {
@@ -112,7 +121,7 @@ struct __attribute__((aligned(16))) TcFeat {
 struct TcLds {
   TcFeat *feat;      // [A] observation features (see TcFeat)
   TcCand *cand;      // [A][K+1] phase-1 lists; afterwards the first K ints of a row = neighbour ids
-  float *x, *y;      // [A] positions after the move (x = +BIG for agents out of the game)
+  float2 *xy;        // [A] positions after the move (x = +BIG for agents out of the game)
   int *sig;          // [A] still_in_the_game before this tick's tagging
   int *tagcnt;       // [A] tags credited to a tagger this tick
   int *types;        // [N]
@@ -122,6 +131,7 @@ struct TcLds {
   int *tstep, *nrun; // [epb]
   float *tfrac;      // [epb] float(t) / episode_length
   int *doneflag;     // [epb] replica finished on this tick (fused tick only)
+  unsigned long long *prof;
 };
 
 #define WD_TC_TAB 64  // capacity of the LDS copies of the action tables
@@ -136,8 +146,7 @@ __device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int 
     bytes = bytes > min_list_bytes ? bytes : min_list_bytes;
     l.cand = (TcCand *)p; p += (bytes + 15) & ~(size_t)15;
   }
-  l.x = (float *)p; p += 4 * A;
-  l.y = (float *)p; p += 4 * A;
+  l.xy = (float2 *)p; p += 8 * A;
   l.sig = (int *)p; p += 4 * A;
   l.tagcnt = (int *)p; p += 4 * A;
   l.types = (int *)p; p += 4 * (size_t)N;
@@ -150,6 +159,35 @@ __device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int 
   l.tfrac = (float *)p; p += 4 * epb;
   l.doneflag = (int *)p;
   return l;
+}
+
+// Copy n floats global -> LDS with every thread's loads in flight before the first LDS write
+// (a plain strided copy loop serialises load -> write per trip: ~1 us per trip at 4 waves/SIMD).
+// src needs 4-byte alignment only; 16-byte vector loads are used on the aligned middle part.
+__device__ __forceinline__ void tc_copy_to_lds(float *dst, const float *__restrict__ src, int n, int tid, int T_) {
+  const int head = min(n, (int)(((16u - ((unsigned)(size_t)src & 15u)) & 15u) >> 2));
+  const int nvec = (n - head) >> 2;
+  const int tail0 = head + 4 * nvec;
+  const float4 *v = (const float4 *)(src + head);
+  constexpr int U = 6;  // vector loads kept in flight per thread per round
+  for (int q0 = 0; q0 < nvec; q0 += U * T_) {
+    float4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u * T_ + tid;
+      if (q < nvec) r[u] = v[q];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u * T_ + tid;
+      if (q < nvec) {
+        float *d = dst + head + 4 * q;
+        d[0] = r[u].x; d[1] = r[u].y; d[2] = r[u].z; d[3] = r[u].w;
+      }
+    }
+  }
+  if (tid < head) dst[tid] = src[tid];
+  if (tid < n - tail0) dst[tail0 + tid] = src[tail0 + tid];
 }
 
 #define WD_BIG 1.0e30f  // (x - BIG)^2 overflows to +inf: such a candidate is never selected
@@ -202,9 +240,9 @@ __device__ __forceinline__ void tc_sort_network(unsigned long long (&key)[n]) {
 // ---- phase 1, register-resident variant (K <= KMAX) --------------------------------
 template <int KMAX>
 __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag, int li, int N, int K) {
-  const float *cx = l.x + el * N, *cy = l.y + el * N;
+  const float2 *cxy = l.xy + el * N;
   TcCand *mine = l.cand + (size_t)li * (K + 1);
-  const float xi = cx[ag], yi = cy[ag];
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
   const float INF = __builtin_inff();
 
   // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
@@ -213,13 +251,17 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) B[k] = INF;
   for (int j = 0; j < N; ++j) {
-    const float dx = xi - cx[j], dy = yi - cy[j];
+    const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
     const float d2 = dx * dx + dy * dy;
 #pragma unroll
     for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], d2);
     B[0] = fminf(B[0], d2);
   }
   if (WD_TC_ABLATE & 4) { ((float *)mine)[0] = B[KMAX]; return; }
+#ifdef WD_TC_PROFILE
+  if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 4] = __builtin_readcyclecounter();
+#endif
   // B[k], k = 1..K are the K smallest squared distances to OTHER agents (B[0] is self or a
   // co-located twin).  T2 = the K-th of them.
   float T2 = INF;
@@ -263,7 +305,8 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
         const int nb = min(32, N - j0);
         unsigned mb = 0u, mu = 0u;
         for (int b = 0; b < nb; ++b) {
-          const float dx = xi - cx[j0 + b], dy = yi - cy[j0 + b];
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
           const float d2 = dx * dx + dy * dy;
           mb = mb + mb + ((d2 < T2lo) ? 1u : 0u);
           mu = mu + mu + ((d2 <= T2hi) ? 1u : 0u);
@@ -291,6 +334,9 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
       sel[w] = lo | tie;
     }
     if (WD_TC_ABLATE & 8) { ((unsigned *)mine)[0] = sel[0] ^ sel[1] ^ sel[2] ^ sel[3]; return; }
+#ifdef WD_TC_PROFILE
+    if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 5] = __builtin_readcyclecounter();
+#endif
     // C. peel the (at most K) ids off the mask in ascending order, rebuild their distances
     //    and form 64-bit keys (float bits of sqrt(d2) << 32 | id)
 #pragma unroll
@@ -304,7 +350,8 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
       sel[1] = (which == 1) ? cleared : sel[1];
       sel[2] = (which == 2) ? cleared : sel[2];
       sel[3] = (which == 3) ? cleared : sel[3];
-      const float dx = xi - cx[j], dy = yi - cy[j];
+      const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
       const unsigned long long sbits =
           have ? (unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000ull;
       key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? j : 0xffff);
@@ -315,7 +362,8 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
     //     was selected (the write after the K-th selection stays inside the row).
     int cnt = 0, tie_taken = 0;
     for (int j = 0; j < N; ++j) {
-      const float dx = xi - cx[j], dy = yi - cy[j];
+      const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
       const float d2 = dx * dx + dy * dy;
       const bool other = (j != ag);
       const bool less = other && (d2 < T2lo);
@@ -334,6 +382,9 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
     }
   }
   tc_sort_network<KMAX>(key);
+#ifdef WD_TC_PROFILE
+  if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 6] = __builtin_readcyclecounter();
+#endif
   int *out = (int *)mine;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
@@ -342,10 +393,10 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
 
 // ---- phase 1, generic K: K passes, each picks the smallest (d, id) key above the previous
 __device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, int li, int N, int K) {
-  const float *cx = l.x + el * N, *cy = l.y + el * N;
+  const float2 *cxy = l.xy + el * N;
   const int *csig = l.sig + el * N;
   int *out = (int *)(l.cand + (size_t)li * (K + 1));
-  const float xi = cx[ag], yi = cy[ag];
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
   float pd = -1.0f;
   int pj = -1;
   for (int k = 0; k < K; ++k) {
@@ -353,7 +404,8 @@ __device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, i
     int bj = -1;
     for (int j = 0; j < N; ++j) {
       if (csig[j] == 0 || j == ag) continue;
-      const float dx = xi - cx[j], dy = yi - cy[j];
+      const float2 pc = cxy[j];
+      const float dx = xi - pc.x, dy = yi - pc.y;
       const float d = sqrtf(dx * dx + dy * dy);
       const bool above = (d > pd) || (d == pd && j > pj);
       if (above && d < best) { best = d; bj = j; }
@@ -378,104 +430,169 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   const TcLds l = tc_carve(smem, epb, N, K, FUSED ? (size_t)4 * epb * N * max(n_acc, n_turn) : 0);
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
+  const_cast<TcLds &>(l).prof = a.prof;
   const int row_ints = 2 * (K + 1);                    // ints per agent row of the id list
   const float two_pi = 6.2831854820251465f;            // float32(2*pi), :356
   const float L = a.grid_length;
   const double diag = (double)L * 1.4142135623730951;  // float32 L * np.sqrt(2) -> f64, :146
   const float sp_div = a.max_speed + 1.0e-10f;         // float32 + float32(eps), :456
 
+  WD_TC_STAMP(0);
   // ---- replica-independent tables: agent types, ascending tagger list, action tables
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
   if (tab_in_lds) {
     for (int i = tid; i < n_acc; i += T_) l.acc_tab[i] = a.acc_actions[i];
     for (int i = tid; i < n_turn; i += T_) l.turn_tab[i] = a.turn_actions[i];
   }
+  int n_taggers = 0;
   {
     // rank of a tagger = number of taggers with a smaller id: wave ballots + per-wave counts
     const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
-    int n_taggers_before = 0;
-    for (int base = 0; base < N; base += T_) {  // one trip unless N > blockDim.x
-      const int i = base + tid;
-      const int ty = (i < N) ? a.agent_types[i] : 0;
-      if (i < N) l.types[i] = ty;
+    if (N <= T_) {  // usual case: one barrier
+      const int ty = (tid < N) ? a.agent_types[tid] : 0;
+      if (tid < N) l.types[tid] = ty;
       const unsigned long long m = __ballot(ty == 1);
       if (lane == 0) l.wave_cnt[wave] = __popcll(m);
       __syncthreads();
-      int before = n_taggers_before;
-      for (int w2 = 0; w2 < wave; ++w2) before += l.wave_cnt[w2];
-      if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
-      for (int w2 = 0; w2 < n_waves; ++w2) n_taggers_before += l.wave_cnt[w2];
-      __syncthreads();
+      int before = 0;
+      for (int w2 = 0; w2 < n_waves; ++w2) {
+        const int c = l.wave_cnt[w2];
+        before += (w2 < wave) ? c : 0;
+        n_taggers += c;
+      }
+      if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+    } else {
+      for (int base = 0; base < N; base += T_) {
+        const int i = base + tid;
+        const int ty = (i < N) ? a.agent_types[i] : 0;
+        if (i < N) l.types[i] = ty;
+        const unsigned long long m = __ballot(ty == 1);
+        if (lane == 0) l.wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = n_taggers;
+        for (int w2 = 0; w2 < wave; ++w2) before += l.wave_cnt[w2];
+        if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        for (int w2 = 0; w2 < n_waves; ++w2) n_taggers += l.wave_cnt[w2];
+        __syncthreads();
+      }
     }
-    if (tid == 0) l.wave_cnt[0] = n_taggers_before;
   }
-  __syncthreads();
-  const int n_taggers = l.wave_cnt[0];
+  // (tagger_ids / action tables are first read after the barriers inside the replica loop)
 
-  for (int env0 = blockIdx.x * epb; env0 < a.E; env0 += gridDim.x * epb) {
+  for (int env0 = a.env_begin + blockIdx.x * epb; env0 < a.E; env0 += gridDim.x * epb) {
     const int env = env0 + el;
     const bool active = (el < epb) && (env < a.E);
     const int gi = env * N + ag;  // index into [E, N] arrays
     const int li = el * N + ag;   // index into LDS arrays
     float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
     int2 sampled = make_int2(0, 0);
+    // every global load of this iteration is issued here, so the HBM latency is paid once
+    int sg = 0;
+    float dir_in = 0.f, acc_in = 0.f, speed_in = 0.f, x_in = 0.f, y_in = 0.f, skill = 0.f;
+    if (active) {
+      sg = a.sig_arr[gi];
+      dir_in = a.direction[gi];
+      acc_in = a.acceleration[gi];
+      speed_in = a.speed[gi];
+      x_in = a.loc_x[gi];
+      y_in = a.loc_y[gi];
+      skill = a.skill_levels[ag];
+      if (!FUSED) sampled = ((const int2 *)a.actions)[gi];
+    }
+    WD_TC_STAMP(1);
 
     // ------------------------------------------- fused tick: sample both action heads
-    // (replaces two sample_actions launches, random.cu:51-85).  The block's rows of a head are
-    // one contiguous slab: coalesced load into LDS (the phase-1 list region is free now), each
-    // thread scans its own row; one Philox call serves both heads.
+    // (replaces two sample_actions launches, random.cu:51-85): inverse CDF on a running
+    // float32 sum, one Philox call for both heads.
     if (FUSED) {
       if (active && ag == 0 && a.done[env] != 0) a.done[env] = 0;  // finished (and reset) last tick
-      const int rows_here = min(epb, a.E - env0) * N;
-      float *slab = (float *)l.cand;
-      wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
-      if (active) {
-        const uint32_t epoch = fz.rng_state[WD_RNG_HEADER + gi];
-        fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
-        rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
-                               fz.rng_state[1]);
-      }
-#pragma unroll
-      for (int head = 0; head < 2; ++head) {
-        const int na = head == 0 ? n_acc : n_turn;
-        const float *src = (head == 0 ? fz.probs_acc : fz.probs_turn) + (long)env0 * N * na;
-        __syncthreads();  // previous users of the slab region are done
-        for (int i = tid; i < rows_here * na; i += T_) slab[i] = src[i];
-        __syncthreads();
+      constexpr int CH = 24;
+      if (n_acc <= CH && n_turn <= CH) {
+        // each thread pulls its own two probability rows straight into registers: all loads in
+        // flight at once, no LDS staging, no barriers (a wavefront's rows are one contiguous
+        // region, so every fetched line is fully used)
+        float pa[CH], pt[CH];
+        uint32_t epoch = 0u;
         if (active) {
-          const float u = wd_u01_open_closed(head == 0 ? rnd.x : rnd.y);
-          const float *pr = slab + (size_t)li * na;
+          const float *ra = fz.probs_acc + (long)gi * n_acc, *rt = fz.probs_turn + (long)gi * n_turn;
+          epoch = fz.rng_state[WD_RNG_HEADER + gi];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) pa[i] = (i < n_acc) ? ra[i] : 0.0f;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) pt[i] = (i < n_turn) ? rt[i] : 0.0f;
+          fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
+          const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u},
+                                             fz.rng_state[0], fz.rng_state[1]);
+          const float u0 = wd_u01_open_closed(rnd.x), u1 = wd_u01_open_closed(rnd.y);
           float cum = 0.0f;
-          int cnt = 0;
-          for (int i = 0; i < na; ++i) {
-            cum = (i == 0) ? pr[0] : cum + pr[i];
-            cnt += (cum < u) ? 1 : 0;
+          int c0 = 0, c1 = 0;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            cum = (i == 0) ? pa[0] : cum + pa[i];
+            c0 += (i < n_acc && cum < u0) ? 1 : 0;
           }
-          const int idx = min(cnt, na - 1);
-          if (head == 0) sampled.x = idx; else sampled.y = idx;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            cum = (i == 0) ? pt[0] : cum + pt[i];
+            c1 += (i < n_turn && cum < u1) ? 1 : 0;
+          }
+          sampled = make_int2(min(c0, n_acc - 1), min(c1, n_turn - 1));
+          ((int2 *)fz.actions_out)[gi] = sampled;
         }
+      } else {
+        // long rows: stage each head's contiguous slab in LDS (the phase-1 list region is free now)
+        const int rows_here = min(epb, a.E - env0) * N;
+        float *slab = (float *)l.cand;
+        wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
+        if (active) {
+          const uint32_t epoch = fz.rng_state[WD_RNG_HEADER + gi];
+          fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
+          rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
+                                 fz.rng_state[1]);
+        }
+#pragma unroll
+        for (int head = 0; head < 2; ++head) {
+          const int na = head == 0 ? n_acc : n_turn;
+          const float *src = (head == 0 ? fz.probs_acc : fz.probs_turn) + (long)env0 * N * na;
+          __syncthreads();  // previous users of the slab region are done
+          tc_copy_to_lds(slab, src, rows_here * na, tid, T_);
+          __syncthreads();
+          if (active) {
+            const float u = wd_u01_open_closed(head == 0 ? rnd.x : rnd.y);
+            const float *pr = slab + (size_t)li * na;
+            float cum = 0.0f;
+            int cnt = 0;
+            for (int i = 0; i < na; ++i) {
+              cum = (i == 0) ? pr[0] : cum + pr[i];
+              cnt += (cum < u) ? 1 : 0;
+            }
+            const int idx = min(cnt, na - 1);
+            if (head == 0) sampled.x = idx; else sampled.y = idx;
+          }
+        }
+        if (active) ((int2 *)fz.actions_out)[gi] = sampled;
+        __syncthreads();  // the slab region becomes the phase-1 list region again
       }
-      if (active) ((int2 *)fz.actions_out)[gi] = sampled;
-      __syncthreads();  // the slab region becomes the phase-1 list region again
     }
+    __syncthreads();  // prologue tables (first iteration) / previous iteration's LDS readers
 
+    WD_TC_STAMP(2);
     // ------------------------------------------------------------ phase 0: move
     if (active) {
-      const int sg = a.sig_arr[gi];
       const float s = (float)sg;
-      const int2 act = FUSED ? sampled : ((const int2 *)a.actions)[gi];
+      const int2 act = sampled;
       const float d_acc = tab_in_lds ? l.acc_tab[act.x] : a.acc_actions[act.x];
       const float d_turn = tab_in_lds ? l.turn_tab[act.y] : a.turn_actions[act.y];
-      const float dir = wd_np_remainderf(a.direction[gi] + d_turn, two_pi) * s;  // :355-357
-      float acc = a.acceleration[gi] + d_acc;                                     // :359
-      const float vmax = a.max_speed * a.skill_levels[ag];                        // :363
-      float v = a.speed[gi] + acc;
+      const float dir = wd_np_remainderf(dir_in + d_turn, two_pi) * s;            // :355-357
+      float acc = acc_in + d_acc;                                                 // :359
+      const float vmax = a.max_speed * skill;                                     // :363
+      float v = speed_in + acc;
       v = fminf(fmaxf(v, 0.0f), vmax) * s;                                        // :364-366
       acc = acc * (v > 0.0f ? 1.0f : 0.0f) * (v < vmax ? 1.0f : 0.0f);            // :367
       float sn, cs;
       wd_np_sincosf(dir, sn, cs);
-      float px = a.loc_x[gi] + v * cs;                                            // :369-374
-      float py = a.loc_y[gi] + v * sn;
+      float px = x_in + v * cs;                                                   // :369-374
+      float py = y_in + v * sn;
       const bool crossed = !((px >= 0.0f) && (px <= L) && (py >= 0.0f) && (py <= L));
       px = fminf(fmaxf(px, 0.0f), L);                                             // :385-391
       py = fminf(fmaxf(py, 0.0f), L);
@@ -490,8 +607,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       my_y = py;
       // agents out of the game are pushed to +BIG for the neighbour search only; every other
       // consumer (taggers are never out of the game) reads real positions
-      l.x[li] = sg ? px : WD_BIG;
-      l.y[li] = py;
+      l.xy[li] = make_float2(sg ? px : WD_BIG, py);
       TcFeat ft;
       ft.nx = (double)px / diag;    // :462 (float64 division)
       ft.ny = (double)py / diag;
@@ -513,6 +629,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
     }
     __syncthreads();
 
+    WD_TC_STAMP(3);
     // ------------------------------------------------ phase 1: K nearest neighbours
     if (!a.use_full_obs && active && !(WD_TC_ABLATE & 1)) {
       if (l.sig[li]) {
@@ -525,6 +642,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
     }
     __syncthreads();
 
+    WD_TC_STAMP(7);
     // ------------------------------------------------ phase 2: observations
     // One work item = (agent row m, neighbour slot k): it reads the neighbour id once, then
     // the 7 features of that neighbour and of the agent, and writes the 7 columns
@@ -610,6 +728,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       }
     }
 
+    WD_TC_STAMP(9);
     // ------------------------------------------------------------ phase 3: rewards
     float rew = 0.0f;
     bool tagged = false, is_runner = false;
@@ -622,7 +741,8 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
         int bt = -1;
         for (int t = 0; t < n_taggers; ++t) {  // ascending ids, first minimum wins :643-651
           const int j = l.tagger_ids[t];
-          const float dx = my_x - l.x[el * N + j], dy = my_y - l.y[el * N + j];
+          const float2 pt = l.xy[el * N + j];
+          const float dx = my_x - pt.x, dy = my_y - pt.y;
           const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
           if (d < best) { best = d; bt = j; }
         }
@@ -651,6 +771,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       }
     }
     __syncthreads();
+    WD_TC_STAMP(10);
     // ------------------------------------------- fused tick: reset finished replicas in place
     // (reset.cu:9-75 for every registered array).  `_done_` stays 1 so the trainer can read
     // which replicas finished on this tick; the next tick clears it.  All writes of this block
@@ -685,7 +806,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       int *num_runners_arr, float kDistanceMarginForReward, float kTagRewardForTagger,            \
       float kTagPenaltyForRunner, float kEndOfGameRewardForRunner, int *done_arr,                 \
       int *env_timestep_arr, int kNumAgents, int kEpisodeLength, int kNumEnvs,                    \
-      int kNumAccelerationActions, int kNumTurnActions
+      int kNumAccelerationActions, int kNumTurnActions, int kEnvBegin
 
 #define WD_TC_PACK()                                                                              \
   TcArgs a;                                                                                       \
@@ -701,8 +822,8 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   a.margin = kDistanceMarginForReward; a.tag_reward = kTagRewardForTagger;                        \
   a.tag_penalty = kTagPenaltyForRunner; a.end_reward = kEndOfGameRewardForRunner;                 \
   a.done = done_arr; a.timestep = env_timestep_arr; a.N = kNumAgents; a.T = kEpisodeLength;       \
-  a.E = kNumEnvs;                                                                                 \
-  (void)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
+  a.E = kNumEnvs; a.env_begin = kEnvBegin;                                                        \
+  a.prof = (unsigned long long *)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
 
 extern "C" {
 

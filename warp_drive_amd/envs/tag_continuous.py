@@ -267,7 +267,9 @@ class TagContinuous(CUDAEnvironmentContext):
         # The reference registers two [N, N-1] scratch arrays the CUDA kernel sorts in HBM
         # (and resets: 2 x 43.7 KB per replica at N = 105).  The HIP kernel selects neighbours
         # in registers, so they shrink to one-element placeholders that keep the names valid.
-        feed.add_data(name="neighbor_distances", data=np.zeros((1,), dtype=np.float32))
+        # (WD_TC_PROFILE builds reuse this pointer for phase time stamps: 16 x uint64 per block)
+        n_prof = 32 * 4096 if os.environ.get("WD_TC_PROFILE") else 1
+        feed.add_data(name="neighbor_distances", data=np.zeros((n_prof,), dtype=np.float32))
         feed.add_data(name="neighbor_ids_sorted_by_distance", data=np.zeros((1,), dtype=np.int32))
         feed.add_data(name="nearest_neighbor_ids", data=np.zeros((n, K), dtype=np.int32),
                       save_copy_and_apply_at_reset=True)
@@ -284,7 +286,7 @@ class TagContinuous(CUDAEnvironmentContext):
         "tag_reward_for_tagger", "tag_penalty_for_runner", "end_of_game_reward_for_runner", "_done_",
         "_timestep_", ("n_agents", "meta"), ("episode_length", "meta"), ("n_envs", "meta"),
         "num_acceleration_actions", "num_turn_actions",
-    ]
+    ]  # + kEnvBegin appended by step_launch / tick_launch
 
     def resolve_step_function_name(self, default_name):
         """Pick the register-resident top-K specialisation that covers K (partial obs only)."""
@@ -315,12 +317,24 @@ class TagContinuous(CUDAEnvironmentContext):
             grid = (min(grid[0], int(os.environ["WD_TC_GRID"])), 1)
         return epb, block, grid
 
-    def step_launch(self):
-        """(function, args, block, grid, shared_bytes) of one device tick."""
+    def _range_args(self, env_range):
+        """step-kernel arguments for replicas [begin, end): kNumEnvs carries `end`, kEnvBegin `begin`"""
+        args = list(self.cuda_step_function_feed(self._STEP_ARGS))
         epb, block, grid = self._geometry()
-        return self.cuda_step, self.cuda_step_function_feed(self._STEP_ARGS), block, grid, self.lds_bytes(epb)
+        if env_range is None:
+            return args + [np.int32(0)], epb, block, grid
+        begin, end = int(env_range[0]), int(env_range[1])
+        n_envs_pos = self._STEP_ARGS.index(("n_envs", "meta"))
+        args[n_envs_pos] = np.int32(end)
+        grid = (max(1, min(grid[0], (end - begin + epb - 1) // epb)), 1)
+        return args + [np.int32(begin)], epb, block, grid
 
-    def tick_launch(self, sampler, probabilities, resetter):
+    def step_launch(self, env_range=None):
+        """(function, args, block, grid, shared_bytes) of one device tick (optionally of a replica range)."""
+        args, epb, block, grid = self._range_args(env_range)
+        return self.cuda_step, args, block, grid, self.lds_bytes(epb)
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None):
         """Fused rollout tick: sample both action heads + step + reset finished replicas in ONE
         launch (HipTagContinuousTick[_K<k>]).  probabilities = [acceleration, turn] float32 CUDA
         tensors [E, N, n_actions].  `_done_` stays set for replicas that finished on the tick
@@ -334,9 +348,8 @@ class TagContinuous(CUDAEnvironmentContext):
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         table, n_arrays = reset_args[0], reset_args[1]
         assert len(probabilities) == 2
-        epb, block, grid = self._geometry()
-        args = list(self.cuda_step_function_feed(self._STEP_ARGS)) + [
-            sampler.rng_state, probabilities[0], probabilities[1], table, n_arrays, _stream_tag("tick")]
+        args, epb, block, grid = self._range_args(env_range)
+        args = args + [sampler.rng_state, probabilities[0], probabilities[1], table, n_arrays, _stream_tag("tick")]
         return fn, args, block, grid, self.lds_bytes(epb, fused=True)
 
     # ------------------------------------------------------------------------------ step

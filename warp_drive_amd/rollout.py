@@ -26,7 +26,8 @@ _ACTIONS = Constants.ACTIONS
 
 
 class RolloutEngine:
-    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True):
+    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
+                 n_groups=1):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform."""
         assert env_wrapper.env_backend == "hip"
@@ -55,6 +56,7 @@ class RolloutEngine:
         self.entry_names = []
         self._graph_ticks = 0
         self.fused = bool(fused and reset_done and hasattr(env_wrapper.env, "tick_launch") and H == 2)
+        self.group_plans, self.group_streams = [], []
         if self.fused:
             # whole tick = ONE launch: sampling, step and reset fused in the env's tick kernel
             fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
@@ -63,6 +65,20 @@ class RolloutEngine:
             self.step_entry = 0
             self.step_kernel_name = fn.name
             self.entry_names.append(fn.name)
+            if n_groups > 1:
+                # Replica groups on separate HIP streams: every group runs its own chain of tick
+                # kernels, so the memory-bound phases of one group (probability reads, observation
+                # writes) overlap the compute-bound neighbour search of another instead of all
+                # blocks marching through the phases in lock step.
+                from warp_drive_amd.distributed import shard_replicas
+
+                for g in range(n_groups):
+                    first, count = shard_replicas(E, n_groups, g)
+                    plan = drv.LaunchPlan()
+                    plan.add(*self._with_shared(env_wrapper.env.tick_launch(
+                        sampler, probabilities, env_wrapper.env_resetter, env_range=(first, first + count))))
+                    self.group_plans.append(plan)
+                    self.group_streams.append(torch.cuda.Stream(device=dev))
             return
         for k, (p, a) in enumerate(zip(probabilities, head_sizes)):
             fn, args, block, grid, shared = sampler.categorical_launch(
@@ -79,8 +95,21 @@ class RolloutEngine:
             self.plan.add(fn, args, block, grid, 0)
             self.entry_names.append(fn.name)
 
+    @staticmethod
+    def _with_shared(launch):
+        fn, args, block, grid, shared = launch
+        return fn, args, block, grid, shared
+
     def run(self, ticks, stream=None):
         """Enqueue `ticks` rollout ticks (asynchronous)."""
+        if self.group_plans:
+            cur = torch.cuda.current_stream()
+            for plan, s in zip(self.group_plans, self.group_streams):
+                s.wait_stream(cur)
+                plan.run(ticks, int(s.cuda_stream))
+            for s in self.group_streams:
+                cur.wait_stream(s)
+            return
         self.plan.run(ticks, stream)
 
     def run_graph(self, ticks, ticks_per_graph=10, stream=None):
