@@ -108,7 +108,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--num-envs", type=int, default=2000, help="replicas per GPU")
+    ap.add_argument("--num-envs", type=int, default=None, help="replicas per GPU (default: the BASELINE config's)")
+    ap.add_argument("--workload", choices=("tag_continuous", "tag_gridworld", "cartpole"), default="tag_continuous",
+                    help="tag_continuous = BASELINE configs[2] (the headline metric); the other two are the "
+                         "configs[1] / configs[4] side workloads quoted in DESIGN.md")
     ap.add_argument("--full-obs", action="store_true", help="use_full_observation=True variant (F = 729)")
     ap.add_argument("--mode", choices=("plan", "graph"), default="plan",
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
@@ -135,9 +138,24 @@ def main():
     from warp_drive_amd.rollout import RolloutEngine
     from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 
-    cfg = dict(BENCH_CFG, use_full_observation=bool(args.full_obs))
-    E = args.num_envs
-    w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip", process_id=local_rank)
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+    from warp_drive_amd.envs.tag_gridworld import CUDATagGridWorld
+
+    if args.workload == "tag_continuous":
+        cfg = dict(BENCH_CFG, use_full_observation=bool(args.full_obs))
+        E = args.num_envs or 2000
+        env_obj = TagContinuous(**cfg)
+    elif args.workload == "tag_gridworld":  # BASELINE configs[1]
+        cfg = dict(num_taggers=4, grid_length=10, episode_length=100, seed=27, wall_hit_penalty=0.1,
+                   tag_reward_for_tagger=10.0, tag_penalty_for_runner=2.0, step_cost_for_tagger=0.01,
+                   use_full_observation=True)
+        E = args.num_envs or 1000
+        env_obj = CUDATagGridWorld(**cfg)
+    else:  # BASELINE configs[4]
+        cfg = dict(episode_length=500, seed=274880)
+        E = args.num_envs or 100000
+        env_obj = CUDAClassicControlCartPoleEnv(**cfg)
+    w = EnvWrapper(env_obj=env_obj, num_envs=E, env_backend="hip", process_id=local_rank)
     w.reset_all_envs()
     sampler = HIPSampler(w.cuda_function_manager)
     sampler.init_random(seed=cfg["seed"] + rank)  # seed + device id, trainer_base.py:249-252
@@ -182,11 +200,22 @@ def main():
     engine.plan.enable_timing(-1, 1, 1)
 
     if rank == 0:
-        N, K = w.n_agents, cfg["num_other_agents_observed"]
-        bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
-        if engine.fused:
-            # the tick kernel also reads both heads' probabilities and reads+writes the RNG epoch
-            bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
+        N = w.n_agents
+        if args.workload == "tag_continuous":
+            K = cfg["num_other_agents_observed"]
+            bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
+            if engine.fused:
+                # the tick kernel also reads both heads' probabilities and reads+writes the RNG epoch
+                bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
+            label = ("BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
+                     f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}")
+            metric = "env steps/sec, TagContinuous 5 taggers x 100 runners"
+        elif args.workload == "tag_gridworld":
+            bytes_per_env_step = 576  # N=5, full obs F=21
+            label, metric = "BASELINE configs[1]: TagGridWorld 10x10, 5 agents, full obs", "env steps/sec, TagGridWorld"
+        else:
+            bytes_per_env_step = 68
+            label, metric = "BASELINE configs[4]: Cartpole-v1 Euler step, 1 agent", "env steps/sec, Cartpole"
         bytes_per_launch = bytes_per_env_step * E
         kern_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
@@ -195,12 +224,13 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(engine.step_kernel_name, {})
-                if rec.get("num_envs") == E and rec.get("full_obs") == bool(args.full_obs):
+                if (args.workload == "tag_continuous" and rec.get("num_envs") == E
+                        and rec.get("full_obs") == bool(args.full_obs)):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "env steps/sec, TagContinuous 5 taggers x 100 runners",
+            "metric": metric,
             "value": world * E * steps / elapsed,
             "unit": "env_steps/s",
             "n_gpus": world,
@@ -213,9 +243,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
-                            f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}, "
-                            f"num_envs={E} per GPU; tick = sample_actions x2 heads + step"
+                "workload": f"{label}, num_envs={E} per GPU; tick = sample_actions ({len(engine.head_sizes)} head"
+                            f"{'s' if len(engine.head_sizes) > 1 else ''}) + step"
                             f"{'' if args.no_reset else ' + reset of finished replicas'}"
                             f"{' (one fused launch)' if engine.fused else ''}",
                 "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode, "replica_groups": args.groups,
@@ -228,9 +257,9 @@ def main():
                 "samples": kern_n,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "tag_continuous":
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
+                out["cpu_baseline"] = cpu_baseline({k: v for k, v in cfg.items()})
             except Exception as err:  # the baseline is reported context, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "env_steps/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {err}"}
