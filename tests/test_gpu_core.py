@@ -343,3 +343,28 @@ def test_cartpole_vs_oracle():
         w.reset_only_done_envs()
         orc.reset_done_envs()
         np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)
+
+
+def test_consistency_checker_api():
+    """The reference's own parity harness, at 1e-5 instead of 1 % (its scenarios:
+    tests/example_envs/pycuda_tests/test_tag_continuous.py:15-80, test_tag_gridworld.py:13-38)."""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.env_cpu_gpu_consistency_checker import EnvironmentCPUvsGPU
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.envs.tag_gridworld import CUDATagGridWorld, TagGridWorld
+
+    require_gpu()
+    tc = {"test2": dict(num_taggers=4, num_runners=1, max_acceleration=0.05, max_turn=np.pi / 4,
+                        num_acceleration_levels=3, num_turn_levels=3, grid_length=10, episode_length=30,
+                        step_penalty_for_tagger=-0.1, seed=428096, skill_level_runner=1, skill_level_tagger=2,
+                        use_full_observation=False, runner_exits_game_after_tagged=False, tagging_distance=0.25),
+          "test3": dict(num_taggers=1, num_runners=4, max_acceleration=2, max_turn=np.pi / 2,
+                        num_acceleration_levels=3, num_turn_levels=3, grid_length=10, episode_length=30,
+                        step_reward_for_runner=0.1, seed=654208, skill_level_runner=1, skill_level_tagger=0.5,
+                        use_full_observation=False, runner_exits_game_after_tagged=True)}
+    EnvironmentCPUvsGPU(dual_mode_env_class=TagContinuous, env_configs=tc, num_envs=2,
+                        num_episodes=2).test_env_reset_and_step(seed=274880)
+    gw = {"full": dict(num_taggers=4, grid_length=4, episode_length=20, seed=27, use_full_observation=True),
+          "partial": dict(num_taggers=4, grid_length=4, episode_length=20, seed=27, use_full_observation=False)}
+    EnvironmentCPUvsGPU(cpu_env_class=TagGridWorld, cuda_env_class=CUDATagGridWorld, env_configs=gw, num_envs=2,
+                        num_episodes=2).test_env_reset_and_step(seed=3)

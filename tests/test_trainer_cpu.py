@@ -1,0 +1,116 @@
+"""Host-side pieces of the A2C/PPO trainer (no GPU): objectives, schedules, model, config merge,
+and the 2-rank gradient all-reduce path (DistributedDataParallel over gloo)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from warp_drive_amd.training.losses import A2C, PPO, discounted_returns
+from warp_drive_amd.training.models import FullyConnected
+from warp_drive_amd.training.param_scheduler import ParamScheduler
+
+
+def test_discounted_returns_stop_at_done():
+    T, E, n, g = 6, 3, 2, 0.9
+    rng = np.random.RandomState(0)
+    r = torch.tensor(rng.randn(T, E, n), dtype=torch.float32)
+    v = torch.tensor(rng.randn(T, E, n), dtype=torch.float32)
+    done = torch.zeros(T, E, dtype=torch.int32)
+    done[2, 1] = 1
+    done[5, 2] = 1
+    got = discounted_returns(r, done, v, g).numpy()
+    want = np.zeros((T, E, n), np.float32)
+    for e in range(E):
+        for a in range(n):
+            nxt = float(r[-1, e, a]) if done[-1, e] else float(v[-1, e, a])
+            want[-1, e, a] = nxt
+            for t in range(T - 2, -1, -1):
+                nxt = float(r[t, e, a]) + (0.0 if done[t, e] else g * nxt)
+                want[t, e, a] = nxt
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_objectives_and_model():
+    torch.manual_seed(0)
+    T, E, n, F = 5, 4, 3, 11
+    model = FullyConnected(F, [4, 6], [16, 16])
+    obs = torch.randn(T, E, n, F)
+    probs, vals = model(obs)
+    assert [tuple(p.shape) for p in probs] == [(T, E, n, 4), (T, E, n, 6)] and tuple(vals.shape) == (T, E, n)
+    for p in probs:
+        np.testing.assert_allclose(p.sum(-1).detach().numpy(), 1.0, rtol=1e-5)
+    actions = torch.stack([torch.randint(0, 4, (T, E, n)), torch.randint(0, 6, (T, E, n))], dim=-1)
+    rewards = torch.randn(T, E, n)
+    done = torch.zeros(T, E, dtype=torch.int32)
+    done[-1] = 1
+    for algo in (A2C(discount_factor_gamma=0.98, vf_loss_coeff=1.0, entropy_coeff=[[0, 0.5], [100, 0.05]]),
+                 PPO(clip_param=0.1, discount_factor_gamma=0.98, normalize_advantage=True, normalize_return=True)):
+        loss, metrics = algo.compute_loss_and_metrics(timestep=50, actions_batch=actions, rewards_batch=rewards,
+                                                      done_flags_batch=done, action_probabilities_batch=probs,
+                                                      value_functions_batch=vals, perform_logging=True)
+        assert torch.isfinite(loss) and "Total loss" in metrics and "Mean entropy" in metrics
+        model.zero_grad()
+        loss.backward(retain_graph=True)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    sched = ParamScheduler([[0, 0.5], [100, 0.05]])
+    assert abs(sched.get_param_value(50) - 0.275) < 1e-9 and sched.get_param_value(1e9) == 0.05
+    assert ParamScheduler(0.3).get_param_value(7) == 0.3
+
+
+def test_config_merge_and_yaml_files():
+    import yaml
+
+    from warp_drive_amd.training.trainer import recursive_merge_config_dicts
+
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "warp_drive_amd", "training",
+                        "run_configs")
+    default = yaml.safe_load(open(os.path.join(base, "default_configs.yaml")))
+    for name in ("tag_continuous", "tag_gridworld", "single_cartpole"):
+        cfg = yaml.safe_load(open(os.path.join(base, f"{name}.yaml")))
+        for pol in cfg["policy"]:
+            merged = recursive_merge_config_dicts(cfg["policy"][pol], default["policy"])
+            assert merged["max_grad_norm"] == 0.5 and "fc_dims" in merged["model"]
+        assert cfg["trainer"]["train_batch_size"] % cfg["trainer"]["num_envs"] == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from warp_drive_amd import distributed as wdd
+
+    wdd.init_process_group(backend="gloo")
+    torch.manual_seed(0)  # identical initial weights, as DDP broadcasts rank 0's anyway
+    model = torch.nn.parallel.DistributedDataParallel(FullyConnected(7, [3], [8]))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    algo = A2C(discount_factor_gamma=0.9, vf_loss_coeff=1.0, entropy_coeff=0.01)
+    g = torch.Generator().manual_seed(100 + rank)  # every rank rolls out its OWN replicas
+    obs = torch.randn(4, 5, 2, 7, generator=g)
+    actions = torch.randint(0, 3, (4, 5, 2, 1), generator=g)
+    rewards = torch.randn(4, 5, 2, generator=g)
+    done = torch.zeros(4, 5, dtype=torch.int32)
+    probs, vals = model(obs)
+    loss, _ = algo.compute_loss_and_metrics(timestep=0, actions_batch=actions, rewards_batch=rewards,
+                                            done_flags_batch=done, action_probabilities_batch=probs,
+                                            value_functions_batch=vals)
+    opt.zero_grad()
+    loss.backward()  # gradient all-reduce (average) across the 2 ranks
+    opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), flat.numpy())
+    wdd.shutdown()
+
+
+def test_ddp_gradient_allreduce_two_ranks(tmp_path):
+    mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / "w_0.npy"), np.load(tmp_path / "w_1.npy")
+    np.testing.assert_array_equal(w0, w1)  # different data, identical parameters after the step

@@ -211,7 +211,7 @@ class CUDADataManager:
         return self._reset_target_to_pool[name]
 
     def _type_warning_helper(self, key, old, new, comment=None):
-        logging.warning(f"{self.__class__.__name__} casts the data '{key}' from type {old} to {new}")
+        logging.info(f"{self.__class__.__name__} casts the data '{key}' from type {old} to {new}")
 
     host_data = property(lambda self: self._host_data)
     scalar_data_list = property(lambda self: self._scalar_data_list)

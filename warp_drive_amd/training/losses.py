@@ -1,0 +1,93 @@
+"""A2C and PPO objectives (reference warp_drive/training/algorithms/policygradient/
+a2c.py:40-194 and ppo.py:42-228): bootstrapped discounted returns that stop at done flags,
+MSE value loss, (clipped) policy-gradient loss, entropy bonus, optional return / advantage
+normalisation across the (env, agent) dimensions.
+
+Batches are [T, E, n(, heads)] tensors that live on the device; nothing here touches the host
+unless `perform_logging` asks for metric scalars."""
+import torch
+from torch import nn
+from torch.distributions import Categorical
+
+from warp_drive_amd.training.param_scheduler import ParamScheduler
+
+_EPSILON = 1.0e-10
+
+
+def discounted_returns(rewards, done_flags, values_detached, gamma):
+    """R_T = done ? r : V_T ; R_t = r_t + (1 - done_t) * gamma * R_{t+1}   (a2c.py:80-95)"""
+    done = (done_flags > 0).to(rewards.dtype)[..., None]  # [T, E, 1]
+    returns = torch.zeros_like(rewards)
+    returns[-1] = done[-1] * rewards[-1] + (1 - done[-1]) * values_detached[-1]
+    for t in range(rewards.shape[0] - 2, -1, -1):
+        returns[t] = rewards[t] + (1 - done[t]) * gamma * returns[t + 1]
+    return returns
+
+
+def _normalise(x):
+    return (x - x.mean(dim=(1, 2), keepdim=True)) / (x.std(dim=(1, 2), keepdim=True) + _EPSILON)
+
+
+class A2C:
+    clip_param = None  # PPO sets it
+
+    def __init__(self, discount_factor_gamma=1.0, normalize_advantage=False, normalize_return=False,
+                 vf_loss_coeff=0.01, entropy_coeff=0.01):
+        assert 0 <= discount_factor_gamma <= 1
+        self.discount_factor_gamma = discount_factor_gamma
+        self.normalize_advantage = normalize_advantage
+        self.normalize_return = normalize_return
+        self.vf_loss_coeff_schedule = ParamScheduler(vf_loss_coeff)
+        self.entropy_coeff_schedule = ParamScheduler(entropy_coeff)
+
+    def _policy_loss(self, log_prob, advantages):
+        return (-log_prob * advantages).mean()
+
+    def compute_loss_and_metrics(self, timestep=None, actions_batch=None, rewards_batch=None,
+                                 done_flags_batch=None, action_probabilities_batch=None,
+                                 value_functions_batch=None, perform_logging=False):
+        values_detached = value_functions_batch.detach()
+        returns = discounted_returns(rewards_batch, done_flags_batch, values_detached, self.discount_factor_gamma)
+        norm_returns = _normalise(returns) if self.normalize_return else returns
+        vf_loss = nn.functional.mse_loss(value_functions_batch, norm_returns)
+        advantages = norm_returns - values_detached
+        norm_adv = _normalise(advantages) if self.normalize_advantage else advantages
+        log_prob, mean_entropy = 0.0, 0.0
+        for h, probs in enumerate(action_probabilities_batch):
+            dist = Categorical(probs)
+            mean_entropy = mean_entropy + dist.entropy().mean()
+            log_prob = log_prob + dist.log_prob(actions_batch[..., h])
+        policy_loss = self._policy_loss(log_prob, norm_adv)
+        vf_c = self.vf_loss_coeff_schedule.get_param_value(timestep)
+        ent_c = self.entropy_coeff_schedule.get_param_value(timestep)
+        loss = policy_loss + vf_c * vf_loss - ent_c * mean_entropy
+        metrics = {}
+        if perform_logging:
+            var_explained = torch.clamp(1 - norm_adv.detach().var() / (norm_returns.detach().var() + _EPSILON), min=-1.0)
+            metrics = {
+                "VF loss coefficient": vf_c, "Entropy coefficient": ent_c, "Total loss": loss.item(),
+                "Policy loss": policy_loss.item(), "Value function loss": vf_loss.item(),
+                "Mean rewards": rewards_batch.mean().item(), "Max. rewards": rewards_batch.max().item(),
+                "Min. rewards": rewards_batch.min().item(),
+                "Mean value function": value_functions_batch.mean().item(),
+                "Mean advantages": advantages.mean().item(),
+                "Mean (norm.) advantages": norm_adv.mean().item(),
+                "Mean (discounted) returns": returns.mean().item(),
+                "Mean normalized returns": norm_returns.mean().item(), "Mean entropy": mean_entropy.item(),
+                "Variance explained by the value function": var_explained.item(),
+            }
+        return loss, metrics
+
+
+class PPO(A2C):
+    def __init__(self, clip_param=0.1, **kwargs):
+        super().__init__(**kwargs)
+        assert 0 <= clip_param <= 1
+        self.clip_param = clip_param
+
+    def _policy_loss(self, log_prob, advantages):
+        # single-epoch PPO exactly as the reference: ratio against the detached same-batch log-prob
+        ratio = torch.exp(log_prob - log_prob.detach())
+        surr1 = ratio * advantages
+        surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * advantages
+        return -torch.minimum(surr1, surr2).mean()

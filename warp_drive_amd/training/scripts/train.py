@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""End-to-end training on the HIP backend (mirror of the reference's
+warp_drive/training/scripts/example_training_script_pycuda.py:41-225).
+
+    python -m warp_drive_amd.training.scripts.train --env tag_continuous [--iters 5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m warp_drive_amd.training.scripts.train --env tag_continuous      # 8 x MI355X, RCCL DDP
+"""
+import argparse
+import logging
+import os
+
+import torch
+import yaml
+
+from warp_drive_amd import distributed as wdd
+from warp_drive_amd.env_wrapper import EnvWrapper
+from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+from warp_drive_amd.envs.tag_continuous import TagContinuous
+from warp_drive_amd.envs.tag_gridworld import CUDATagGridWorld
+from warp_drive_amd.training.trainer import Trainer
+
+_CONFIGS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "run_configs")
+_ENVS = {"tag_continuous": TagContinuous, "tag_gridworld": CUDATagGridWorld,
+         "single_cartpole": CUDAClassicControlCartPoleEnv}
+
+
+def policy_map_for(name, env):
+    if name == "tag_continuous":  # agent_type 1 = tagger
+        return {"tagger": sorted(env.taggers), "runner": sorted(env.runners)}
+    if name == "tag_gridworld":  # the last agent is the runner
+        return {"tagger": list(range(env.num_taggers)), "runner": [env.num_agents - 1]}
+    return {"shared": list(range(env.num_agents))}
+
+
+def setup_trainer(env_name, overrides=None, results_dir=None, verbose=True):
+    config = yaml.safe_load(open(os.path.join(_CONFIGS, f"{env_name}.yaml")))
+    for section, kv in (overrides or {}).items():
+        config.setdefault(section, {}).update(kv)
+    rank, local_rank, world = wdd.rank_info()
+    torch.cuda.set_device(local_rank)
+    wdd.init_process_group(backend="nccl", device_id=local_rank)
+    env_cfg = dict(config["env"])
+    if "seed" in env_cfg and env_name != "single_cartpole":
+        env_cfg["seed"] = env_cfg["seed"]  # identical start state on every rank; actions differ by seed + rank
+    env = _ENVS[env_name](**env_cfg)
+    wrapper = EnvWrapper(env_obj=env, num_envs=int(config["trainer"]["num_envs"]), env_backend="hip",
+                         process_id=local_rank)
+    return Trainer(env_wrapper=wrapper, config=config, policy_tag_to_agent_id_map=policy_map_for(env_name, env),
+                   device_id=local_rank, results_dir=results_dir, verbose=verbose)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", "-e", choices=sorted(_ENVS), default="tag_continuous")
+    ap.add_argument("--iters", type=int, default=None, help="training iterations (default: from num_episodes)")
+    ap.add_argument("--num_envs", type=int, default=None)
+    ap.add_argument("--train_batch_size", type=int, default=None)
+    ap.add_argument("--results_dir", default=None)
+    args = ap.parse_args()
+    logging.getLogger().setLevel(logging.WARNING)
+    overrides = {"trainer": {k: v for k, v in (("num_envs", args.num_envs),
+                                               ("train_batch_size", args.train_batch_size)) if v is not None}}
+    trainer = setup_trainer(args.env, overrides, args.results_dir)
+    trainer.train(args.iters)
+    trainer.graceful_close()
+    if trainer.rank == 0:
+        print(trainer.perf_stats.get_perf_stats())
+    wdd.shutdown()
+
+
+if __name__ == "__main__":
+    main()

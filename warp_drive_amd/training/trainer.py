@@ -1,0 +1,301 @@
+"""Device-resident A2C / PPO trainer for the HIP rollout engine.
+
+Mirror of reference warp_drive/training/trainers/{trainer_base,trainer_a2c}.py (config keys,
+metric names, checkpoint naming), restructured so the rollout loop never synchronises with the
+host: the reference pulls `done_flags.any()` to the host and synchronises three times per tick
+(trainer_base.py:398-426); here a tick is
+
+    policy forward (torch, obs read in place)  ->  probabilities written in place
+    fused tick kernel (sample all heads + env step + reset of finished replicas; 1 launch)
+    rewards / done / actions copied into the [T, E, n] batch tensors (torch, same stream)
+
+and the only host round trips are the optional metric reads every `metrics_log_freq`
+iterations.  Multi-GPU: one process per GPU, each with its own replicas and seed + rank; the
+models are wrapped in DistributedDataParallel (backend "nccl" = RCCL over xGMI), so the only
+collective is the bucketed gradient all-reduce (trainer_a2c.py:137-146).
+"""
+import json
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from warp_drive_amd import distributed as wdd
+from warp_drive_amd.managers.function_manager import HIPSampler
+from warp_drive_amd.rollout import RolloutEngine
+from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+from warp_drive_amd.training.losses import A2C, PPO
+from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
+from warp_drive_amd.utils.constants import Constants
+
+_ACTIONS, _REWARDS, _OBSERVATIONS = Constants.ACTIONS, Constants.REWARDS, Constants.OBSERVATIONS
+_DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "run_configs", "default_configs.yaml")
+
+
+def recursive_merge_config_dicts(config, default_config):
+    """fill `config` with every key of `default_config` it lacks (trainer_base.py:46-60)"""
+    assert isinstance(config, dict) and isinstance(default_config, dict)
+    for key, default in default_config.items():
+        if key not in config:
+            config[key] = default
+        elif isinstance(default, dict) and isinstance(config[key], dict):
+            recursive_merge_config_dicts(config[key], default)
+    return config
+
+
+class PerfStats:
+    """wall-time split of the training loop (trainer_base.py:849-887)"""
+
+    def __init__(self):
+        self.iters = 0
+        self.steps = 0
+        self.rollout_time = 0.0
+        self.training_time = 0.0
+
+    def get_perf_stats(self):
+        total = self.rollout_time + self.training_time
+        return {
+            "Mean rollout time per iter (ms)": 1e3 * self.rollout_time / max(self.iters, 1),
+            "Mean training time per iter (ms)": 1e3 * self.training_time / max(self.iters, 1),
+            "Mean steps per sec (rollout)": self.steps / max(self.rollout_time, 1e-9),
+            "Mean steps per sec (training time)": self.steps / max(self.training_time, 1e-9),
+            "Mean steps per sec (total)": self.steps / max(total, 1e-9),
+        }
+
+
+class Trainer:
+    def __init__(self, env_wrapper=None, config=None, policy_tag_to_agent_id_map=None, device_id=0,
+                 results_dir=None, verbose=True):
+        assert env_wrapper is not None and env_wrapper.env_backend == "hip"
+        assert config is not None and "trainer" in config and "policy" in config
+        self.w = env_wrapper
+        self.verbose = verbose
+        self.rank, _, self.world = wdd.rank_info()
+        self.device = torch.device("cuda", device_id)
+        defaults = yaml.safe_load(open(_DEFAULT_CONFIG))
+        for key, default in defaults.items():
+            if key == "policy":
+                for pol in config["policy"]:
+                    recursive_merge_config_dicts(config["policy"][pol], default)
+            else:
+                config[key] = recursive_merge_config_dicts(config.get(key, {}), default)
+        self.config = config
+        E = env_wrapper.n_envs
+        if policy_tag_to_agent_id_map is None:
+            policy_tag_to_agent_id_map = {"shared": list(range(env_wrapper.n_agents))}
+        self.policy_map = {k: list(v) for k, v in policy_tag_to_agent_id_map.items()}
+        self.policies = list(self.policy_map)
+        assert set(self.policies) == set(config["policy"]), "every policy needs a config entry"
+        tcfg = config["trainer"]
+        self.num_envs = E
+        self.batch_len = max(1, int(tcfg["train_batch_size"]) // E)  # ticks per training iteration
+        self.train_batch_size = self.batch_len * E
+        self.num_iters = int(tcfg["num_episodes"]) * env_wrapper.episode_length // self.batch_len
+        self.save_dir = results_dir or os.path.join(config["saving"]["basedir"], config["saving"]["name"],
+                                                    config["saving"]["tag"], str(int(time.time())))
+        if self.rank == 0:
+            os.makedirs(self.save_dir, exist_ok=True)
+            json.dump(config, open(os.path.join(self.save_dir, "run_config.json"), "w"), indent=2, default=str)
+
+        # ---- device data: first reset pushes the env arrays, then the placeholders
+        env_wrapper.reset_all_envs()
+        self.sampler = HIPSampler(env_wrapper.cuda_function_manager)
+        self.sampler.init_random(seed=wdd.rank_seed(tcfg.get("seed", 0) or 0, self.rank) + 1)
+        create_and_push_data_placeholders(env_wrapper=env_wrapper, action_sampler=self.sampler,
+                                          policy_tag_to_agent_id_map=self.policy_map,
+                                          training_batch_size_per_env=self.batch_len,
+                                          push_data_batch_placeholders=True)
+        dm = env_wrapper.cuda_data_manager
+        self.obs = dm.data_on_device_via_torch(_OBSERVATIONS)
+        self.actions = dm.data_on_device_via_torch(_ACTIONS)
+        self.rewards = dm.data_on_device_via_torch(_REWARDS)
+        self.done = dm.data_on_device_via_torch("_done_")
+        self.done_batch = dm.data_on_device_via_torch(f"{Constants.DONE_FLAGS}_batch")
+        self.head_sizes = action_head_sizes(env_wrapper.env.action_space[0])
+        N = env_wrapper.n_agents
+        # policy output lives in fixed tensors the tick kernel reads in place
+        self.probs = [torch.full((E, N, a), 1.0 / a, dtype=torch.float32, device=self.device) for a in self.head_sizes]
+        self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True)
+        if not self.engine.fused:
+            # envs without a fused tick kernel: the reset launch clears `_done_`, so it runs after the
+            # flags were copied into the batch (still device-side, no host sync)
+            self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=False)
+
+        # ---- models, optimisers, objectives
+        self.models, self.optimizers, self.trainers, self.ids = {}, {}, {}, {}
+        self.current_timestep = {}
+        for pol in self.policies:
+            pcfg = config["policy"][pol]
+            ids = self.policy_map[pol]
+            obs_size = flattened_obs_size(env_wrapper.env.observation_space[ids[0]])
+            model = FullyConnected(obs_size, self.head_sizes, pcfg["model"]["fc_dims"]).to(self.device)
+            self.current_timestep[pol] = 0
+            ckpt = pcfg["model"].get("model_ckpt_filepath", "")
+            if ckpt:
+                self.load_model_checkpoint({pol: ckpt}, models={pol: model})
+            if self.world > 1 and torch.distributed.is_initialized():
+                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device_id])
+            self.models[pol] = model
+            self.ids[pol] = torch.tensor(ids, dtype=torch.long, device=self.device)
+            self.optimizers[pol] = torch.optim.Adam(model.parameters(), lr=pcfg["lr"])
+            common = dict(discount_factor_gamma=pcfg["gamma"], normalize_advantage=pcfg["normalize_advantage"],
+                          normalize_return=pcfg["normalize_return"], vf_loss_coeff=pcfg["vf_loss_coeff"],
+                          entropy_coeff=pcfg["entropy_coeff"])
+            algo = pcfg["algorithm"].upper()
+            if algo == "A2C":
+                self.trainers[pol] = A2C(**common)
+            elif algo == "PPO":
+                self.trainers[pol] = PPO(clip_param=pcfg["clip_param"], **common)
+            else:
+                raise NotImplementedError(f"algorithm {algo}: only A2C and PPO are supported")
+        self.batch = {
+            pol: {
+                "obs": dm.data_on_device_via_torch(f"{Constants.PROCESSED_OBSERVATIONS}_batch_{pol}")
+                if self.batch_len > 1 else torch.zeros((1, E, len(self.policy_map[pol]),
+                                                        flattened_obs_size(env_wrapper.env.observation_space[
+                                                            self.policy_map[pol][0]])), device=self.device),
+                "actions": dm.data_on_device_via_torch(f"{_ACTIONS}_batch_{pol}"),
+                "rewards": dm.data_on_device_via_torch(f"{_REWARDS}_batch_{pol}"),
+            } for pol in self.policies
+        }
+        # episodic reward bookkeeping, all on the device
+        self._ep_reward = {p: torch.zeros((E, len(self.policy_map[p])), device=self.device) for p in self.policies}
+        self._ep_sum = {p: torch.zeros((), device=self.device) for p in self.policies}
+        self._ep_cnt = torch.zeros((), device=self.device)
+        self.perf_stats = PerfStats()
+        self.metrics = {}
+
+    # --------------------------------------------------------------------------- rollout
+    @torch.no_grad()
+    def _generate_rollout_batch(self):
+        for b in range(self.batch_len):
+            flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
+            for pol in self.policies:
+                ids = self.ids[pol]
+                obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
+                self.batch[pol]["obs"][b].copy_(obs_p)
+                probs, _ = self.models[pol](obs_p)
+                for h, p in enumerate(probs):
+                    if len(self.policies) == 1:
+                        self.probs[h].copy_(p)
+                    else:
+                        self.probs[h].index_copy_(1, ids, p)
+            self.engine.run(1)  # sample + step (+ reset when fused), asynchronous on torch's stream
+            self.done_batch[b].copy_(self.done)
+            if not self.engine.fused:
+                self.w.reset_only_done_envs()
+            finished = (self.done > 0).to(torch.float32)
+            for pol in self.policies:
+                ids = self.ids[pol]
+                a = self.actions if len(self.policies) == 1 else self.actions.index_select(1, ids)
+                r = self.rewards if len(self.policies) == 1 else self.rewards.index_select(1, ids)
+                self.batch[pol]["actions"][b].copy_(a)
+                self.batch[pol]["rewards"][b].copy_(r)
+                self._ep_reward[pol] += r
+                self._ep_sum[pol] += (self._ep_reward[pol].mean(dim=1) * finished).sum()
+                self._ep_reward[pol] *= (1.0 - finished)[:, None]
+            self._ep_cnt += finished.sum()
+
+    # ---------------------------------------------------------------------------- update
+    def _update_model_params(self, iteration, log):
+        metrics = {}
+        done = self.done_batch
+        for pol in self.policies:
+            pcfg = self.config["policy"][pol]
+            if not pcfg["to_train"]:
+                continue
+            batch = self.batch[pol]
+            probs, values = self.models[pol](batch["obs"][: self.batch_len])
+            loss, m = self.trainers[pol].compute_loss_and_metrics(
+                timestep=self.current_timestep[pol], actions_batch=batch["actions"].long(),
+                rewards_batch=batch["rewards"], done_flags_batch=done, action_probabilities_batch=probs,
+                value_functions_batch=values, perform_logging=log)
+            self.optimizers[pol].zero_grad(set_to_none=True)
+            loss.backward()  # DDP: bucketed gradient all-reduce over RCCL overlaps this backward
+            if pcfg["clip_grad_norm"]:
+                torch.nn.utils.clip_grad_norm_(self.models[pol].parameters(), pcfg["max_grad_norm"])
+            self.optimizers[pol].step()
+            self.current_timestep[pol] += self.train_batch_size
+            if log:
+                m["Current timestep"] = self.current_timestep[pol]
+                m["Learning rate"] = pcfg["lr"]
+                cnt = float(self._ep_cnt.item())
+                m["Mean episodic reward"] = float(self._ep_sum[pol].item()) / cnt if cnt > 0 else float("nan")
+                metrics[pol] = m
+        return metrics
+
+    # ----------------------------------------------------------------------------- train
+    def train(self, num_iters=None):
+        iters = self.num_iters if num_iters is None else int(num_iters)
+        log_freq = int(self.config["saving"]["metrics_log_freq"])
+        save_freq = int(self.config["saving"]["model_params_save_freq"])
+        for it in range(iters):
+            log = (it % log_freq == 0) or (it == iters - 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self._generate_rollout_batch()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            metrics = self._update_model_params(it, log)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            self.perf_stats.iters += 1
+            self.perf_stats.steps += self.train_batch_size
+            self.perf_stats.rollout_time += t1 - t0
+            self.perf_stats.training_time += t2 - t1
+            if log:
+                self.metrics = metrics
+                self._log_metrics(it, metrics)
+                for pol in self.policies:
+                    self._ep_sum[pol].zero_()
+                self._ep_cnt.zero_()
+            if save_freq > 0 and ((it + 1) % save_freq == 0 or it == iters - 1):
+                self.save_model_checkpoint()
+        return self.metrics
+
+    def _log_metrics(self, iteration, metrics):
+        record = {"Iterations Completed": iteration + 1, **{p: m for p, m in metrics.items()},
+                  "perf": self.perf_stats.get_perf_stats()}
+        name = "results.json" if self.world == 1 else f"results_device_{self.rank}.json"
+        if self.rank == 0 or self.world > 1:
+            os.makedirs(self.save_dir, exist_ok=True)
+            with open(os.path.join(self.save_dir, name), "a") as f:
+                f.write(json.dumps(record) + "\n")
+        if self.verbose and self.rank == 0:
+            perf = record["perf"]
+            head = ", ".join(f"{p}: loss {m['Total loss']:.4f} ep.rew {m['Mean episodic reward']:.3f}"
+                             for p, m in metrics.items())
+            logging.warning(f"[iter {iteration + 1}] {head} | rollout {perf['Mean steps per sec (rollout)']:.3e} "
+                            f"steps/s, total {perf['Mean steps per sec (total)']:.3e} steps/s")
+
+    # ------------------------------------------------------------------------ checkpoints
+    def _unwrap(self, model):
+        return model.module if hasattr(model, "module") else model
+
+    def save_model_checkpoint(self):
+        """`{policy}_{timestep}.state_dict`, rank 0 only (trainer_a2c.py:361-384)"""
+        if self.rank != 0:
+            return
+        for pol in self.policies:
+            path = os.path.join(self.save_dir, f"{pol}_{self.current_timestep[pol]}.state_dict")
+            torch.save(self._unwrap(self.models[pol]).state_dict(), path)
+
+    def load_model_checkpoint(self, ckpts_dict, models=None):
+        """resume from `{policy}_{timestep}.state_dict`; the timestep is parsed from the name
+        (trainer_a2c.py:341-359)"""
+        models = models or {p: self._unwrap(m) for p, m in self.models.items()}
+        for pol, path in ckpts_dict.items():
+            assert os.path.isfile(path), f"invalid model checkpoint path {path}"
+            models[pol].load_state_dict(torch.load(path, map_location=self.device))
+            stem = os.path.basename(path).split(".state_dict")[0]
+            try:
+                self.current_timestep[pol] = int(stem.split("_")[-1])
+            except ValueError:
+                pass
+
+    def graceful_close(self):
+        torch.cuda.synchronize()
+        wdd.barrier()
