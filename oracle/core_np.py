@@ -85,3 +85,36 @@ def undo_done_flag_and_reset_timestep(done, timestep, force_reset=False):
     d[mask] = 0
     t[mask] = 0
     return d, t
+
+
+# ---------------------------------------------------------------------------------------------
+# Counter-based uniform draws of the HIP sampler (Philox4x32-10, Salmon et al. SC'11).  The
+# reference draws from curand's per-thread XORWOW state (random.cu:14-23,72), which has no CPU
+# counterpart in the reference; this restates OUR generator so the device sampler can be checked
+# draw-for-draw: same (seed, row, epoch, stream tag) -> same u -> same action index.
+# ---------------------------------------------------------------------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over numpy uint32 arrays c0..c3; k0, k1 scalars.  Returns 4 uint32 arrays."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & 0xFFFFFFFF for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = c0 * np.uint64(M0), c2 * np.uint64(M1)
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & 0xFFFFFFFF, p1 >> np.uint64(32), p1 & 0xFFFFFFFF
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def u01_open_closed(bits):
+    """uint32 -> float32 uniform in (0, 1] with 24 random bits (curand_uniform's range)."""
+    return ((np.asarray(bits, dtype=np.uint32) >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
+
+
+def fused_tick_uniforms(n_rows, epochs, seed_lo, seed_hi, stream_tag):
+    """The two uniforms (head 0, head 1) the fused tick kernel draws for every agent row:
+    one Philox call, counter (row, epoch, stream_tag, 3), key (seed_lo, seed_hi)."""
+    rows = np.arange(n_rows, dtype=np.uint32)
+    x, y, _, _ = philox4x32_10(rows, np.asarray(epochs, dtype=np.uint32), np.uint32(stream_tag), np.uint32(3),
+                               seed_lo, seed_hi)
+    return u01_open_closed(x), u01_open_closed(y)

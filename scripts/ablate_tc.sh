@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/ablate
 FLAGS="--offload-arch=gfx950 --genco -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math"
-for v in ${VARIANTS:-0 1 2 3 4 8}; do
+for v in ${VARIANTS:-0 1 2 3 16 64}; do
   out=build/ablate/wd_kernels_ab$v.hsaco
   [ -f $out ] || hipcc $FLAGS -DWD_TC_ABLATE=$v warp_drive_amd/csrc/kernels/wd_kernels.hip -o $out
   if [ "$1" = "run" ]; then

@@ -49,5 +49,9 @@ for fused in (True, False):
             d = st[:, k] - st[:, prev]
             print(f"{names[k]:<22} mean={d.mean():10.0f} p10={np.percentile(d,10):9.0f} p90={np.percentile(d,90):9.0f}")
         prev = k
+    real = (st[:, 12] - st[:, 11]) * 10.0  # ns (100 MHz constant counter)
+    print(f"block lifetime: {real.mean()/1000:.2f} us wall = {(st[:, 10] - st[:, 0]).mean():.0f} shader cycles"
+          f" -> shader clock {(st[:, 10] - st[:, 0]).mean() / real.mean():.3f} GHz;"
+          f" first start -> last end {(st[:, 12].max() - st[:, 11].min()) / 100.0:.2f} us")
     tot = st[:, 10] - st[:, 0]
     print(f"{'total':<22} mean={tot.mean():10.0f}   spread of block start = {st[:,0].max()-st[:,0].min()}")

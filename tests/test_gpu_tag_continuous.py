@@ -232,10 +232,23 @@ def test_fused_tick_kernel(full_obs):
     stats = {"near_tie_rows": 0, "rows": 0}
     counts = [np.zeros(7), np.zeros(9)]
     finished_total = 0
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import _stream_tag
+
+    rng_words = np.zeros(4 + E * N, dtype=np.uint32)
+    probs_host = [p.cpu().numpy() for p in probs]
     for t in range(40):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        assert (rng_words[4:] == t).all()  # one epoch per tick and agent row
         engine.run(1)
         torch.cuda.synchronize()
         a = pull(w, "sampled_actions")
+        # draw-for-draw: the kernel's Philox uniforms restated on the CPU -> identical indices
+        u0, u1 = fused_tick_uniforms(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
+        np.testing.assert_array_equal(a[..., 0], sample_actions_counting(probs_host[0], u0.reshape(E, N)))
+        np.testing.assert_array_equal(a[..., 1], sample_actions_counting(probs_host[1], u1.reshape(E, N)))
         assert a[..., 0].max() < 7 and a[..., 1].max() < 9 and a.min() >= 0
         counts[0] += np.bincount(a[..., 0].reshape(-1), minlength=7)
         counts[1] += np.bincount(a[..., 1].reshape(-1), minlength=9)

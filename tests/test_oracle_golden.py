@@ -185,3 +185,19 @@ def test_c_step_matches_reference(golden_dir, tag):
         for k, v in (("speed", 0), ("acceleration", 0), ("edge_pen", 0), ("sig", 1),
                      ("num_runners", orc.num_runners0), ("timestep", 0), ("done", 0)):
             st[k][m] = v
+
+
+def test_philox_known_answers():
+    """Random123's published known-answer vectors for philox4x32-10 (kat_vectors) pin the
+    generator the device sampler and its CPU restatement share."""
+    from oracle.core_np import philox4x32_10, u01_open_closed
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(*[np.uint32(c) for c in ctr], *key)
+        assert tuple(int(g) for g in got) == want
+    u = u01_open_closed(np.array([0, 0xFFFFFFFF, 0x80000000], dtype=np.uint32))
+    assert u.dtype == np.float32 and u[0] == np.float32(2.0 ** -24) and u[1] == 1.0 and u[2] == np.float32(0.5) + np.float32(2.0 ** -24)

@@ -51,12 +51,42 @@
 // -DWD_TC_PROFILE: thread 0 of every block stores s_memtime stamps at the phase boundaries into
 // the (otherwise unused) neighbor_distances array, 16 x uint64 per block (scripts/phase_profile.py).
 #ifdef WD_TC_PROFILE
-#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && a.prof) a.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && a.prof) { a.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+    if ((slot) == 0) a.prof[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime(); \
+    if ((slot) == 10) a.prof[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define WD_TC_STAMP(slot) do { } while (0)
 #endif
 
+// Start cohorts (see tc_step_impl): number of cohorts, block-id shift that selects the cohort,
+// start offset between consecutive cohorts in ns.
+#ifndef WD_TC_COHORTS
+#define WD_TC_COHORTS 1
+#endif
+#ifndef WD_TC_COHORT_SHIFT
+#define WD_TC_COHORT_SHIFT 8
+#endif
+#ifndef WD_TC_COHORT_NS
+#define WD_TC_COHORT_NS 4000
+#endif
+
+// Store policy of the observation rows (timing experiments: scripts/store_policy_tc.sh).
+// 0 = plain write-back stores, 1 = non-temporal, 2 = system-scope write-through.
+#ifndef WD_TC_OBS_STORE
+#define WD_TC_OBS_STORE 0
+#endif
+
 namespace {
+
+__device__ __forceinline__ void tc_store_obs(float *p, float v) {
+#if WD_TC_OBS_STORE == 1
+  __builtin_nontemporal_store(v, p);
+#elif WD_TC_OBS_STORE == 2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  *p = v;
+#endif
+}
 
 struct TcArgs {
   float *loc_x, *loc_y, *speed, *direction, *acceleration;
@@ -136,19 +166,24 @@ struct TcLds {
 
 #define WD_TC_TAB 64  // capacity of the LDS copies of the action tables
 
-__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K, size_t min_list_bytes) {
+__device__ __forceinline__ size_t tc_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// The per-trip work area (features, lists, positions, flags) doubles as the two probability slabs
+// of the fused tick, which are dead before phase 0 writes it: min_area_bytes = both slabs.
+__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K, size_t min_area_bytes) {
   TcLds l;
   const size_t A = (size_t)epb * N;
+  unsigned char *const p0 = p;
   l.feat = (TcFeat *)p; p += sizeof(TcFeat) * A;
-  {
-    // the list region doubles as the probability slab of the fused tick
-    size_t bytes = 8 * A * (K + 1);
-    bytes = bytes > min_list_bytes ? bytes : min_list_bytes;
-    l.cand = (TcCand *)p; p += (bytes + 15) & ~(size_t)15;
-  }
+  l.cand = (TcCand *)p; p += tc_align16(8 * A * (K + 1));
   l.xy = (float2 *)p; p += 8 * A;
   l.sig = (int *)p; p += 4 * A;
   l.tagcnt = (int *)p; p += 4 * A;
+  {
+    size_t area = (size_t)(p - p0);
+    area = area > min_area_bytes ? area : min_area_bytes;
+    p = p0 + tc_align16(area);
+  }
   l.types = (int *)p; p += 4 * (size_t)N;
   l.tagger_ids = (int *)p; p += 4 * (size_t)N;
   l.acc_tab = (float *)p; p += 4 * WD_TC_TAB;
@@ -188,6 +223,91 @@ __device__ __forceinline__ void tc_copy_to_lds(float *dst, const float *__restri
   }
   if (tid < head) dst[tid] = src[tid];
   if (tid < n - tail0) dst[tail0 + tid] = src[tail0 + tid];
+}
+
+// ---- fused tick: probability slab of ONE wavefront.  The rows of a wavefront's 64 agents are one
+// contiguous run of 64*n floats.  It goes global -> LDS directly (global_load_lds_dwordx4: per-lane
+// global address, LDS destination = wave-uniform base + lane*16; dword-aligned sources are enough),
+// 1 KiB per instruction, fully coalesced, no staging registers, asynchronous until the
+// `s_waitcnt vmcnt(0)` before the rows are read back (stride n dwords).  Producer and consumer are
+// the same wavefront: no block barrier.  A per-thread row walk instead costs 2n uncoalesced load
+// instructions per thread, each touching 64 rows (measured: 13 k of the tick's 74 k cycles).
+#define WD_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define WD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+__device__ __forceinline__ void tc_slab_fetch(float *dst, const float *__restrict__ src, int cnt, int lane) {
+  const int nvec = cnt >> 2;
+  const int nchunk = (nvec + 63) >> 6;  // wave-uniform
+  for (int c = 0; c < nchunk; ++c) {
+    const int q = c * 64 + lane;
+    if (q < nvec) __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * q), WD_LDS_PTR(dst + 256 * c), 16, 0, 0);
+  }
+  if (lane < (cnt & 3))  // the < 4 floats after the last vector
+    __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * nvec + lane), WD_LDS_PTR(dst + 4 * nvec), 4, 0, 0);
+}
+
+// inverse CDF on a running float32 sum (random.cu:51-85): number of prefix sums < u, clamped
+constexpr int TC_CH = 24;  // rows up to this length are read back with all LDS loads in flight
+__device__ __forceinline__ int tc_slab_sample(const float *row, int n, float u) {
+  int cnt = 0;
+  float cum = 0.0f;
+  if (n <= TC_CH) {
+    float p[TC_CH];
+#pragma unroll
+    for (int i = 0; i < TC_CH; ++i) p[i] = row[i];  // immediate offsets; entries >= n are the next row's
+                                                    // (or, after the last row, table bytes): read, never used
+#pragma unroll
+    for (int i = 0; i < TC_CH; ++i) {
+      cum = (i == 0) ? p[0] : cum + p[i];
+      cnt += (i < n && cum < u) ? 1 : 0;
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      cum = (i == 0) ? row[0] : cum + row[i];
+      cnt += (cum < u) ? 1 : 0;
+    }
+  }
+  return min(cnt, n - 1);
+}
+
+// every global input of one loop trip; issued together so the HBM latency is paid once
+struct TcIn {
+  int sg;
+  float dir, acc, speed, x, y, skill;
+  int2 sampled;
+  uint32_t epoch;
+};
+
+template <bool FUSED>
+__device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const TcFuse &fz, int env0, int epb,
+                                               int N, int n_acc, int n_turn, int tid, float *slab_acc,
+                                               float *slab_turn) {
+  const int el = tid / N, ag = tid - el * N;
+  const int env = env0 + el;
+  const bool active = (el < epb) && (env < a.E);
+  const int gi = env * N + ag;
+  in.sg = 0; in.dir = in.acc = in.speed = in.x = in.y = in.skill = 0.f;
+  in.sampled = make_int2(0, 0);
+  in.epoch = 0u;
+  if (active) {
+    in.sg = a.sig_arr[gi];
+    in.dir = a.direction[gi];
+    in.acc = a.acceleration[gi];
+    in.speed = a.speed[gi];
+    in.x = a.loc_x[gi];
+    in.y = a.loc_y[gi];
+    in.skill = a.skill_levels[ag];
+    if (!FUSED) in.sampled = ((const int2 *)a.actions)[gi];
+    if (FUSED) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
+  }
+  if (FUSED) {
+    // this wavefront's rows of both probability slabs -> LDS
+    const int rows_here = min(epb, a.E - env0) * N;
+    const int r0 = (tid >> 6) * 64, lane = tid & 63;
+    const int wrows = max(0, min(64, rows_here - r0));
+    tc_slab_fetch(slab_acc + (size_t)r0 * n_acc, fz.probs_acc + ((long)env0 * N + r0) * n_acc, wrows * n_acc, lane);
+    tc_slab_fetch(slab_turn + (size_t)r0 * n_turn, fz.probs_turn + ((long)env0 * N + r0) * n_turn, wrows * n_turn,
+                  lane);
+  }
 }
 
 #define WD_BIG 1.0e30f  // (x - BIG)^2 overflows to +inf: such a candidate is never selected
@@ -427,7 +547,10 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   const int W = a.use_full_obs ? (N - 1) : K;  // columns per feature
   const int F = 7 * W + 1;
   const int epb = max(1, (int)blockDim.x / N);
-  const TcLds l = tc_carve(smem, epb, N, K, FUSED ? (size_t)4 * epb * N * max(n_acc, n_turn) : 0);
+  const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
+  const TcLds l = tc_carve(smem, epb, N, K,
+                           FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
+  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const_cast<TcLds &>(l).prof = a.prof;
@@ -437,7 +560,25 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   const double diag = (double)L * 1.4142135623730951;  // float32 L * np.sqrt(2) -> f64, :146
   const float sp_div = a.max_speed + 1.0e-10f;         // float32 + float32(eps), :456
 
+#if WD_TC_COHORTS > 1
+  // Start cohort: blocks of different cohorts begin WD_TC_COHORT_NS apart, so that the memory-bound
+  // phases (probability fetch, observation stores) of one cohort run under the VALU-bound neighbour
+  // search of another instead of all blocks marching through the phases in lock step.
+  {
+    const unsigned cohort = (blockIdx.x >> WD_TC_COHORT_SHIFT) % WD_TC_COHORTS;
+    if (cohort) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long wait = (unsigned long long)cohort * (WD_TC_COHORT_NS / 10);
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(2);
+    }
+  }
+#endif
   WD_TC_STAMP(0);
+  // the first trip's global loads go out before anything else: the table set-up below (a
+  // dependent global load + barrier) then runs in their shadow
+  TcIn in;
+  tc_issue_loads<FUSED>(in, a, fz, a.env_begin + blockIdx.x * epb, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
+
   // ---- replica-independent tables: agent types, ascending tagger list, action tables
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
   if (tab_in_lds) {
@@ -479,100 +620,41 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   }
   // (tagger_ids / action tables are first read after the barriers inside the replica loop)
 
-  for (int env0 = a.env_begin + blockIdx.x * epb; env0 < a.E; env0 += gridDim.x * epb) {
+  // rotated loop: the loads of trip i+1 are issued at the end of trip i, so `in` is live only
+  // from issue to use (never across the body)
+  int env0 = a.env_begin + blockIdx.x * epb;
+  if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
+  while (true) {
     const int env = env0 + el;
     const bool active = (el < epb) && (env < a.E);
     const int gi = env * N + ag;  // index into [E, N] arrays
     const int li = el * N + ag;   // index into LDS arrays
     float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
-    int2 sampled = make_int2(0, 0);
-    // every global load of this iteration is issued here, so the HBM latency is paid once
-    int sg = 0;
-    float dir_in = 0.f, acc_in = 0.f, speed_in = 0.f, x_in = 0.f, y_in = 0.f, skill = 0.f;
-    if (active) {
-      sg = a.sig_arr[gi];
-      dir_in = a.direction[gi];
-      acc_in = a.acceleration[gi];
-      speed_in = a.speed[gi];
-      x_in = a.loc_x[gi];
-      y_in = a.loc_y[gi];
-      skill = a.skill_levels[ag];
-      if (!FUSED) sampled = ((const int2 *)a.actions)[gi];
-    }
+    const int sg = in.sg;
+    const float dir_in = in.dir, acc_in = in.acc, speed_in = in.speed, x_in = in.x, y_in = in.y, skill = in.skill;
+    int2 sampled = in.sampled;
     WD_TC_STAMP(1);
 
     // ------------------------------------------- fused tick: sample both action heads
     // (replaces two sample_actions launches, random.cu:51-85): inverse CDF on a running
     // float32 sum, one Philox call for both heads.
     if (FUSED) {
-      if (active && ag == 0 && a.done[env] != 0) a.done[env] = 0;  // finished (and reset) last tick
-      constexpr int CH = 24;
-      if (n_acc <= CH && n_turn <= CH) {
-        // each thread pulls its own two probability rows straight into registers: all loads in
-        // flight at once, no LDS staging, no barriers (a wavefront's rows are one contiguous
-        // region, so every fetched line is fully used)
-        float pa[CH], pt[CH];
-        uint32_t epoch = 0u;
-        if (active) {
-          const float *ra = fz.probs_acc + (long)gi * n_acc, *rt = fz.probs_turn + (long)gi * n_turn;
-          epoch = fz.rng_state[WD_RNG_HEADER + gi];
-#pragma unroll
-          for (int i = 0; i < CH; ++i) pa[i] = (i < n_acc) ? ra[i] : 0.0f;
-#pragma unroll
-          for (int i = 0; i < CH; ++i) pt[i] = (i < n_turn) ? rt[i] : 0.0f;
-          fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
-          const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u},
-                                             fz.rng_state[0], fz.rng_state[1]);
-          const float u0 = wd_u01_open_closed(rnd.x), u1 = wd_u01_open_closed(rnd.y);
-          float cum = 0.0f;
-          int c0 = 0, c1 = 0;
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            cum = (i == 0) ? pa[0] : cum + pa[i];
-            c0 += (i < n_acc && cum < u0) ? 1 : 0;
-          }
-#pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            cum = (i == 0) ? pt[0] : cum + pt[i];
-            c1 += (i < n_turn && cum < u1) ? 1 : 0;
-          }
-          sampled = make_int2(min(c0, n_acc - 1), min(c1, n_turn - 1));
-          ((int2 *)fz.actions_out)[gi] = sampled;
-        }
-      } else {
-        // long rows: stage each head's contiguous slab in LDS (the phase-1 list region is free now)
-        const int rows_here = min(epb, a.E - env0) * N;
-        float *slab = (float *)l.cand;
-        wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
-        if (active) {
-          const uint32_t epoch = fz.rng_state[WD_RNG_HEADER + gi];
-          fz.rng_state[WD_RNG_HEADER + gi] = epoch + 1u;
-          rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
-                                 fz.rng_state[1]);
-        }
-#pragma unroll
-        for (int head = 0; head < 2; ++head) {
-          const int na = head == 0 ? n_acc : n_turn;
-          const float *src = (head == 0 ? fz.probs_acc : fz.probs_turn) + (long)env0 * N * na;
-          __syncthreads();  // previous users of the slab region are done
-          tc_copy_to_lds(slab, src, rows_here * na, tid, T_);
-          __syncthreads();
-          if (active) {
-            const float u = wd_u01_open_closed(head == 0 ? rnd.x : rnd.y);
-            const float *pr = slab + (size_t)li * na;
-            float cum = 0.0f;
-            int cnt = 0;
-            for (int i = 0; i < na; ++i) {
-              cum = (i == 0) ? pr[0] : cum + pr[i];
-              cnt += (cum < u) ? 1 : 0;
-            }
-            const int idx = min(cnt, na - 1);
-            if (head == 0) sampled.x = idx; else sampled.y = idx;
-          }
-        }
-        if (active) ((int2 *)fz.actions_out)[gi] = sampled;
-        __syncthreads();  // the slab region becomes the phase-1 list region again
+      if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
+      wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
+      if (active) {
+        fz.rng_state[WD_RNG_HEADER + gi] = in.epoch + 1u;
+        rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, in.epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
+                               fz.rng_state[1]);
       }
+      // every global_load_lds of this wavefront has landed once its vmcnt drains; the rows a lane
+      // reads were all fetched by its own wavefront
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (active) {
+        sampled.x = tc_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
+        sampled.y = tc_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
+      }
+      if (active) ((int2 *)fz.actions_out)[gi] = sampled;
     }
     __syncthreads();  // prologue tables (first iteration) / previous iteration's LDS readers
 
@@ -700,7 +782,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
           if (acc == 123.456f) row[0] = acc;
         } else {
 #pragma unroll
-          for (int c = 0; c < 7; ++c) row[c * W + k] = vals[c];
+          for (int c = 0; c < 7; ++c) tc_store_obs(row + c * W + k, vals[c]);
         }
         // advance (m, i, k) by the block stride
         k += sk;
@@ -713,7 +795,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
       if (!(WD_TC_ABLATE & 32))
       for (int m0 = tid; m0 < agents_here; m0 += T_)
-        obs_blk[(long)m0 * F + 7 * W] = (l.sig[m0] != 0) ? l.tfrac[m0 / N] : 0.0f;
+        tc_store_obs(obs_blk + (long)m0 * F + 7 * W, (l.sig[m0] != 0) ? l.tfrac[m0 / N] : 0.0f);
       if (!a.use_full_obs && K > 0 && !(WD_TC_ABLATE & 32)) {
         int *nb_blk = a.nearest_ids + (long)env0 * N * K;
         int k2 = tid % K, m2 = tid / K;
@@ -789,6 +871,9 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       }
       __syncthreads();
     }
+    env0 += gridDim.x * epb;
+    if (env0 >= a.E) break;
+    tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
   }
 }
 
@@ -856,26 +941,26 @@ __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
 
 // register-resident top-K specialisations (blocks of <= 512 threads); the host picks the
 // smallest KMAX >= K and falls back to the generic entry for > 512 agents per replica
-#define WD_TC_SPECIALISE(KM)                                                                   \
-  __global__ void __launch_bounds__(512) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
+#define WD_TC_SPECIALISE(KM, WAVES)                                                                 \
+  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     tc_step_impl<KM, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
   }                                                                                            \
-  __global__ void __launch_bounds__(512) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     WD_TC_FUSE_PACK();                                                                         \
     tc_step_impl<KM, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);          \
   }
-WD_TC_SPECIALISE(2)
-WD_TC_SPECIALISE(4)
-WD_TC_SPECIALISE(6)
-WD_TC_SPECIALISE(8)
-WD_TC_SPECIALISE(10)
-WD_TC_SPECIALISE(12)
-WD_TC_SPECIALISE(16)
-WD_TC_SPECIALISE(24)
-WD_TC_SPECIALISE(32)
+WD_TC_SPECIALISE(2, 4)
+WD_TC_SPECIALISE(4, 4)
+WD_TC_SPECIALISE(6, 4)
+WD_TC_SPECIALISE(8, 4)
+WD_TC_SPECIALISE(10, 4)
+WD_TC_SPECIALISE(12, 3)
+WD_TC_SPECIALISE(16, 3)
+WD_TC_SPECIALISE(24, 2)
+WD_TC_SPECIALISE(32, 2)
 
 }  // extern "C"

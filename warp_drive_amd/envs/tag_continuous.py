@@ -302,11 +302,13 @@ class TagContinuous(CUDAEnvironmentContext):
         N = self.num_agents
         A = epb * N
         K = 0 if self.use_full_observation else self.num_other_agents_observed
-        lists = 8 * A * (K + 1)
-        if fused:  # the list region doubles as the probability slab
-            lists = max(lists, 4 * A * max(len(self.acceleration_actions), len(self.turn_actions)))
-        lists = (lists + 15) // 16 * 16
-        return 48 * A + lists + 4 * 4 * A + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16
+        def align16(v):
+            return (v + 15) // 16 * 16
+
+        area = 48 * A + align16(8 * A * (K + 1)) + 4 * 4 * A   # features, lists, positions + 2 flag arrays
+        if fused:  # the work area doubles as the two probability slabs (global_load_lds targets)
+            area = max(area, align16(4 * A * len(self.acceleration_actions)) + align16(4 * A * len(self.turn_actions)))
+        return align16(area) + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16
 
     def _geometry(self):
         # 256 threads = one wavefront per SIMD: measured 1.3x faster than the denser 320-thread

@@ -14,6 +14,8 @@ fixed LaunchPlan replayed from C (or captured once into a hipGraph):
 The probability tensors the sampler reads are whatever the policy wrote last (torch
 tensors aliased in place); for kernel-only throughput they are constant uniform tensors.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -104,8 +106,14 @@ class RolloutEngine:
         """Enqueue `ticks` rollout ticks (asynchronous)."""
         if self.group_plans:
             cur = torch.cuda.current_stream()
-            for plan, s in zip(self.group_plans, self.group_streams):
+            stagger_us = float(os.environ.get("WD_STAGGER_US", "0"))
+            for g, (plan, s) in enumerate(zip(self.group_plans, self.group_streams)):
                 s.wait_stream(cur)
+                if stagger_us > 0 and g > 0:  # start the groups out of phase
+                    fm = self.w.cuda_function_manager
+                    fm.initialize_functions(["wd_delay"])
+                    fm.get_function("wd_delay")(np.uint64(int(100 * stagger_us * g)), block=(1, 1, 1), grid=(1, 1),
+                                                stream=int(s.cuda_stream))
                 plan.run(ticks, int(s.cuda_stream))
             for s in self.group_streams:
                 cur.wait_stream(s)
