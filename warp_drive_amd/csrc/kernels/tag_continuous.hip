@@ -406,52 +406,88 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
     T2hi = th;
     T2lo = tl;
   }
-  int c_less = 0;  // others strictly below the range
-#pragma unroll
-  for (int k = 1; k <= KMAX; ++k) c_less += (k <= K && B[k] < T2lo) ? 1 : 0;
-  const int need_tie = K - c_less;
-
   unsigned long long key[KMAX];
   if (N <= 128) {
-    // B. second pass: two 128-bit per-lane masks, "below the range" and "inside or below the
-    //    range".  Each candidate costs a squared distance, two compares and two
-    //    shift-in-the-carry adds (m = 2m + bit); no LDS traffic, no data-dependent addressing.
-    //    Candidate b of word w lands on bit (nb-1-b): undone with one bit-reverse per word.
-    unsigned below[4] = {0u, 0u, 0u, 0u}, upto[4] = {0u, 0u, 0u, 0u};
+    // B. second pass: one 128-bit per-lane mask "inside or below the range".  Each candidate costs
+    //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no LDS
+    //    traffic, no data-dependent addressing.  Candidate b of word w lands on bit (nb-1-b):
+    //    undone with one bit-reverse per word.
+    unsigned sel[4] = {0u, 0u, 0u, 0u};
+    int n_upto = 0;
+    // (loop-invariant across trips, but hoisting them costs long-lived registers the kernel does not
+    // have at 128 VGPRs: the empty asm statements pin their computation here)
+    int ag_here = ag, n_here = N;
+    asm volatile("" : "+v"(ag_here));
+    asm volatile("" : "+s"(n_here));
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int j0 = 32 * w;
-      if (j0 < N) {  // wave-uniform
-        const int nb = min(32, N - j0);
-        unsigned mb = 0u, mu = 0u;
-        for (int b = 0; b < nb; ++b) {
+      if (j0 < n_here) {  // wave-uniform
+        const int nb = min(32, n_here - j0);
+        unsigned mu = 0u;
+        // m = 2m + (d2 <= T2hi): compare into VCC, add with carry-in (2 VALU ops per candidate).
+        // Unrolled by hand (loops holding inline asm are not unrolled by the compiler) so the four
+        // LDS reads of a group are in flight together.
+#define WD_TC_PUSH(m, d2v, thr, op) \
+  asm("v_cmp_" op "_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(thr) : "vcc")
+        int b = 0;
+        for (; b + 4 <= nb; b += 4) {
+          const float2 p0 = cxy[j0 + b], p1 = cxy[j0 + b + 1], p2 = cxy[j0 + b + 2], p3 = cxy[j0 + b + 3];
+          const float ax = xi - p0.x, ay = yi - p0.y, bx = xi - p1.x, by = yi - p1.y;
+          const float cx = xi - p2.x, cy = yi - p2.y, ex = xi - p3.x, ey = yi - p3.y;
+          const float d0 = ax * ax + ay * ay, d1 = bx * bx + by * by, d2 = cx * cx + cy * cy, d3 = ex * ex + ey * ey;
+          WD_TC_PUSH(mu, d0, T2hi, "le");
+          WD_TC_PUSH(mu, d1, T2hi, "le");
+          WD_TC_PUSH(mu, d2, T2hi, "le");
+          WD_TC_PUSH(mu, d3, T2hi, "le");
+        }
+        for (; b < nb; ++b) {
           const float2 pj = cxy[j0 + b];
           const float dx = xi - pj.x, dy = yi - pj.y;
           const float d2 = dx * dx + dy * dy;
-          mb = mb + mb + ((d2 < T2lo) ? 1u : 0u);
-          mu = mu + mu + ((d2 <= T2hi) ? 1u : 0u);
+          WD_TC_PUSH(mu, d2, T2hi, "le");
         }
-        below[w] = __brev(mb) >> (32 - nb);
-        upto[w] = __brev(mu) >> (32 - nb);
+        const unsigned self_bit = ((ag_here >> 5) == w) ? (1u << (ag_here & 31)) : 0u;
+        sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
+        n_upto += __popc(sel[w]);
       }
     }
-    // selected = below | first `need_tie` members (ascending id) of the range; never self
-    unsigned sel[4];
-    int quota = need_tie;
+    // Usually exactly K others are inside or below the range and the mask is the answer.  More
+    // than K means several candidates share the K-th float32 distance: the reference keeps the
+    // lowest ids among them (stable heapq.nsmallest, :435-437).  Rare (a float32 sqrt tie at the
+    // cut), so the "strictly below" mask is only built then.
+    if (n_upto > K) {
+      unsigned lo[4] = {0u, 0u, 0u, 0u};
+      int c_less = 0;  // others strictly below the range
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
-      const unsigned lo = below[w] & ~self_bit;
-      unsigned tie = upto[w] & ~below[w] & ~self_bit;
-      // keep the lowest `quota` set bits of tie (ties are rare: the loop almost never runs)
-      const int have_t = __popc(tie);
-      if (have_t > quota) {
-        unsigned kept = 0u;
-        for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
-        tie = kept;
+      for (int w = 0; w < 4; ++w) {
+        const int j0 = 32 * w;
+        if (j0 < n_here) {
+          const int nb = min(32, n_here - j0);
+          unsigned mb = 0u;
+          for (int b = 0; b < nb; ++b) {
+            const float2 pj = cxy[j0 + b];
+            const float dx = xi - pj.x, dy = yi - pj.y;
+            const float d2 = dx * dx + dy * dy;
+            WD_TC_PUSH(mb, d2, T2lo, "lt");
+          }
+          lo[w] = (__brev(mb) >> (32 - nb)) & sel[w];
+          c_less += __popc(lo[w]);
+        }
       }
-      quota -= min(have_t, quota);
-      sel[w] = lo | tie;
+      int quota = K - c_less;  // members of the range still to take, ascending id
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned tie = sel[w] & ~lo[w];
+        const int have_t = __popc(tie);
+        if (have_t > quota) {  // keep the lowest `quota` set bits
+          unsigned kept = 0u;
+          for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
+          tie = kept;
+        }
+        quota -= min(have_t, quota);
+        sel[w] = lo[w] | tie;
+      }
     }
     if (WD_TC_ABLATE & 8) { ((unsigned *)mine)[0] = sel[0] ^ sel[1] ^ sel[2] ^ sel[3]; return; }
 #ifdef WD_TC_PROFILE
@@ -480,6 +516,13 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
     // B'. more than 128 agents: same selection, collected in a (K+1)-slot LDS row.  Branch-free:
     //     every candidate is written to the next free slot and the slot only advances when it
     //     was selected (the write after the K-th selection stays inside the row).
+    int c_less = 0;  // others strictly below the range (counting pre-pass)
+    for (int j = 0; j < N; ++j) {
+      const float2 pc = cxy[j];
+      const float dx = xi - pc.x, dy = yi - pc.y;
+      c_less += (j != ag && (dx * dx + dy * dy) < T2lo) ? 1 : 0;
+    }
+    const int need_tie = K - c_less;
     int cnt = 0, tie_taken = 0;
     for (int j = 0; j < N; ++j) {
       const float2 pj = cxy[j];
