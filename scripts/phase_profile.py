@@ -9,9 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "build", "prof")
 os.makedirs(out, exist_ok=True)
-hsaco = os.path.join(out, "wd_kernels_prof.hsaco")
+ablate = os.environ.get("ABLATE", "0")  # WD_TC_ABLATE bits (timing-only variants)
+hsaco = os.path.join(out, f"wd_kernels_prof{ablate}.hsaco")
 subprocess.run(["hipcc", "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
-                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-DWD_TC_PROFILE",
+                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-DWD_TC_PROFILE", f"-DWD_TC_ABLATE={ablate}",
                 os.path.join(ROOT, "warp_drive_amd/csrc/kernels/wd_kernels.hip"), "-o", hsaco], check=True)
 os.environ["WD_HSACO"] = hsaco
 os.environ["WD_TC_PROFILE"] = "1"
@@ -34,8 +35,13 @@ create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, trainin
                                   push_data_batch_placeholders=False)
 for fused in (True, False):
     engine = RolloutEngine(w, sampler, fused=fused)
+    import time
     engine.run(50)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    engine.run(2000)
+    torch.cuda.synchronize()
+    print(f"=== ablate={ablate}: wall per tick {(time.perf_counter() - t0) / 2000 * 1e6:.2f} us")
     raw = w.cuda_data_manager.pull_data_from_device("neighbor_distances").view(np.uint64).reshape(-1, 16)
     n_blocks = 1000
     st = raw[:n_blocks].astype(np.int64)
@@ -55,3 +61,14 @@ for fused in (True, False):
           f" first start -> last end {(st[:, 12].max() - st[:, 11].min()) / 100.0:.2f} us")
     tot = st[:, 10] - st[:, 0]
     print(f"{'total':<22} mean={tot.mean():10.0f}   spread of block start = {st[:,0].max()-st[:,0].min()}")
+
+# two replica groups on two HIP streams: do their kernels overlap in time?
+engine = RolloutEngine(w, sampler, fused=True, n_groups=2)
+engine.run(50)
+torch.cuda.synchronize()
+raw = w.cuda_data_manager.pull_data_from_device("neighbor_distances").view(np.uint64).reshape(-1, 16)
+st = raw[:1000].astype(np.int64)
+t0 = st[:, 11].min()
+for g, sl in enumerate((slice(0, 500), slice(500, 1000))):
+    print(f"group {g}: last tick blocks start {(st[sl, 11].min() - t0) / 100.0:8.2f} us .. end {(st[sl, 12].max() - t0) / 100.0:8.2f} us "
+          f"(mean block lifetime {((st[sl, 12] - st[sl, 11]).mean()) / 100.0:.2f} us)")

@@ -51,9 +51,9 @@
 // -DWD_TC_PROFILE: thread 0 of every block stores s_memtime stamps at the phase boundaries into
 // the (otherwise unused) neighbor_distances array, 16 x uint64 per block (scripts/phase_profile.py).
 #ifdef WD_TC_PROFILE
-#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && a.prof) { a.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
-    if ((slot) == 0) a.prof[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime(); \
-    if ((slot) == 10) a.prof[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && l.prof) { l.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+    if ((slot) == 0) l.prof[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime(); \
+    if ((slot) == 10) l.prof[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define WD_TC_STAMP(slot) do { } while (0)
 #endif
@@ -71,7 +71,7 @@
 #endif
 
 // Store policy of the observation rows (timing experiments: scripts/store_policy_tc.sh).
-// 0 = plain write-back stores, 1 = non-temporal, 2 = system-scope write-through.
+// 0 = plain write-back stores, 1 = non-temporal, 2 = system-scope, 3 = agent-scope write-through.
 #ifndef WD_TC_OBS_STORE
 #define WD_TC_OBS_STORE 0
 #endif
@@ -83,6 +83,8 @@ __device__ __forceinline__ void tc_store_obs(float *p, float v) {
   __builtin_nontemporal_store(v, p);
 #elif WD_TC_OBS_STORE == 2
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif WD_TC_OBS_STORE == 3
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
   *p = v;
 #endif
@@ -170,29 +172,26 @@ __device__ __forceinline__ size_t tc_align16(size_t v) { return (v + 15) & ~(siz
 
 // The per-trip work area (features, lists, positions, flags) doubles as the two probability slabs
 // of the fused tick, which are dead before phase 0 writes it: min_area_bytes = both slabs.
-__device__ __forceinline__ TcLds tc_carve(unsigned char *p, int epb, int N, int K, size_t min_area_bytes) {
+__device__ __forceinline__ TcLds tc_carve(unsigned char *p0, int epb, int N, int K, size_t min_area_bytes) {
+  // offsets only (no pointer differences: they turn LDS pointers into flat ones and back)
   TcLds l;
   const size_t A = (size_t)epb * N;
-  unsigned char *const p0 = p;
-  l.feat = (TcFeat *)p; p += sizeof(TcFeat) * A;
-  l.cand = (TcCand *)p; p += tc_align16(8 * A * (K + 1));
-  l.xy = (float2 *)p; p += 8 * A;
-  l.sig = (int *)p; p += 4 * A;
-  l.tagcnt = (int *)p; p += 4 * A;
-  {
-    size_t area = (size_t)(p - p0);
-    area = area > min_area_bytes ? area : min_area_bytes;
-    p = p0 + tc_align16(area);
-  }
-  l.types = (int *)p; p += 4 * (size_t)N;
-  l.tagger_ids = (int *)p; p += 4 * (size_t)N;
-  l.acc_tab = (float *)p; p += 4 * WD_TC_TAB;
-  l.turn_tab = (float *)p; p += 4 * WD_TC_TAB;
-  l.wave_cnt = (int *)p; p += 4 * 16;
-  l.tstep = (int *)p; p += 4 * epb;
-  l.nrun = (int *)p; p += 4 * epb;
-  l.tfrac = (float *)p; p += 4 * epb;
-  l.doneflag = (int *)p;
+  size_t off = 0;
+  l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
+  l.cand = (TcCand *)(p0 + off); off += tc_align16(8 * A * (K + 1));
+  l.xy = (float2 *)(p0 + off); off += 8 * A;
+  l.sig = (int *)(p0 + off); off += 4 * A;
+  l.tagcnt = (int *)(p0 + off); off += 4 * A;
+  off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
+  l.types = (int *)(p0 + off); off += 4 * (size_t)N;
+  l.tagger_ids = (int *)(p0 + off); off += 4 * (size_t)N;
+  l.acc_tab = (float *)(p0 + off); off += 4 * WD_TC_TAB;
+  l.turn_tab = (float *)(p0 + off); off += 4 * WD_TC_TAB;
+  l.wave_cnt = (int *)(p0 + off); off += 4 * 16;
+  l.tstep = (int *)(p0 + off); off += 4 * epb;
+  l.nrun = (int *)(p0 + off); off += 4 * epb;
+  l.tfrac = (float *)(p0 + off); off += 4 * epb;
+  l.doneflag = (int *)(p0 + off);
   return l;
 }
 
@@ -596,7 +595,8 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
-  const_cast<TcLds &>(l).prof = a.prof;
+  // (profiling builds: a launch over replicas [env_begin, E) stamps the rows of its own blocks)
+  const_cast<TcLds &>(l).prof = a.prof ? a.prof + (size_t)(a.env_begin / epb) * 16 : nullptr;
   const int row_ints = 2 * (K + 1);                    // ints per agent row of the id list
   const float two_pi = 6.2831854820251465f;            // float32(2*pi), :356
   const float L = a.grid_length;
@@ -706,8 +706,13 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
     if (active) {
       const float s = (float)sg;
       const int2 act = sampled;
-      const float d_acc = tab_in_lds ? l.acc_tab[act.x] : a.acc_actions[act.x];
-      const float d_turn = tab_in_lds ? l.turn_tab[act.y] : a.turn_actions[act.y];
+      // (value select, not pointer select: a pointer that may be LDS or global becomes a flat access)
+      float d_acc = l.acc_tab[min(act.x, WD_TC_TAB - 1)], d_turn = l.turn_tab[min(act.y, WD_TC_TAB - 1)];
+      asm volatile("" : "+v"(d_acc), "+v"(d_turn));  // keeps the two loads from being merged into one flat load
+      if (!tab_in_lds) {
+        d_acc = a.acc_actions[act.x];
+        d_turn = a.turn_actions[act.y];
+      }
       const float dir = wd_np_remainderf(dir_in + d_turn, two_pi) * s;            // :355-357
       float acc = acc_in + d_acc;                                                 // :359
       const float vmax = a.max_speed * skill;                                     // :363
