@@ -117,6 +117,9 @@ def main():
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
+    ap.add_argument("--ticks-per-launch", type=int, default=1,
+                    help="Cartpole only: env ticks fused into one launch (fixed-policy rollout; SURVEY 8(d) "
+                         "asks the ceiling run to fuse T ticks); a bench 'step' is then one launch = T ticks")
     ap.add_argument("--groups", type=int, default=1,
                     help="replica groups on separate HIP streams (fused tick only): overlaps the memory-bound "
                          "phases of one group with the neighbour search of another")
@@ -155,6 +158,7 @@ def main():
         cfg = dict(episode_length=500, seed=274880)
         E = args.num_envs or 100000
         env_obj = CUDAClassicControlCartPoleEnv(**cfg)
+        env_obj.ticks_per_launch = max(1, args.ticks_per_launch)
     w = EnvWrapper(env_obj=env_obj, num_envs=E, env_backend="hip", process_id=local_rank)
     w.reset_all_envs()
     sampler = HIPSampler(w.cuda_function_manager)
@@ -204,9 +208,6 @@ def main():
         if args.workload == "tag_continuous":
             K = cfg["num_other_agents_observed"]
             bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
-            if engine.fused:
-                # the tick kernel also reads both heads' probabilities and reads+writes the RNG epoch
-                bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
             label = ("BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
                      f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}")
             metric = "env steps/sec, TagContinuous 5 taggers x 100 runners"
@@ -216,7 +217,10 @@ def main():
         else:
             bytes_per_env_step = 68
             label, metric = "BASELINE configs[4]: Cartpole-v1 Euler step, 1 agent", "env steps/sec, Cartpole"
-        bytes_per_launch = bytes_per_env_step * E
+        if engine.fused:
+            # a fused tick kernel also reads every head's probabilities and reads+writes the RNG epoch
+            bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
+        bytes_per_launch = bytes_per_env_step * E * engine.ticks_per_launch
         kern_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic = None
@@ -231,7 +235,7 @@ def main():
                 traffic = None
         out = {
             "metric": metric,
-            "value": world * E * steps / elapsed,
+            "value": world * E * steps * engine.ticks_per_launch / elapsed,
             "unit": "env_steps/s",
             "n_gpus": world,
             "steps": steps,
@@ -248,7 +252,8 @@ def main():
                             f"{'' if args.no_reset else ' + reset of finished replicas'}"
                             f"{' (one fused launch)' if engine.fused else ''}",
                 "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode, "replica_groups": args.groups,
-                "kernels_per_tick": len(engine.entry_names), "parallelism": f"env-replica sharding x{world}",
+                "kernels_per_tick": len(engine.entry_names), "ticks_per_launch": engine.ticks_per_launch,
+                "parallelism": f"env-replica sharding x{world}",
             },
             "roofline": {
                 "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,

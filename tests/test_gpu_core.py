@@ -345,6 +345,59 @@ def test_cartpole_vs_oracle():
         np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)
 
 
+@pytest.mark.parametrize("ticks", [1, 4])
+def test_cartpole_fused_tick(ticks):
+    """HipClassicControlCartPoleEnvTick: sampling + step + in-kernel reset, `ticks` ticks per launch.
+    The CPU side replays the kernel's Philox draws tick by tick through the oracle."""
+    import torch
+    from oracle.cartpole_np import CartPoleOracle
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from tests.hip_harness import OBS, REW, make_wrapper, pull, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    require_gpu()
+    E, T = 3001, 40
+    env = CUDAClassicControlCartPoleEnv(episode_length=T, seed=32145)
+    env.ticks_per_launch = ticks
+    w = make_wrapper(env, E)
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=9)  # (placeholders were pushed by the harness)
+    rng = np.random.RandomState(1)
+    probs = torch.from_numpy(rng.dirichlet(np.ones(2), size=(E, 1)).astype(np.float32)).cuda()
+    engine = RolloutEngine(w, sampler, probabilities=[probs])
+    assert engine.fused and engine.ticks_per_launch == ticks and len(engine.entry_names) == 1
+    orc = CartPoleOracle(E, T, initial_state=pull(w, "state")[0, 0])
+    rng_words = np.zeros(4 + E, dtype=np.uint32)
+    probs_host = probs.cpu().numpy()
+    finished = 0
+    for launch in range(40):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        assert (rng_words[4:] == launch * ticks).all()
+        engine.run(1)
+        torch.cuda.synchronize()
+        for k in range(ticks):
+            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            a = sample_actions_counting(probs_host, u.reshape(E, 1))
+            orc.step(a.reshape(E, 1, 1))
+            last = k == ticks - 1
+            if last:  # what the launch leaves in HBM is its last tick
+                np.testing.assert_array_equal(pull(w, "sampled_actions")[:, 0, 0], a[:, 0])
+                np.testing.assert_array_equal(pull(w, "_done_"), orc.done)
+                np.testing.assert_array_equal(pull(w, REW)[:, 0], orc.rewards)
+                fin = orc.done > 0
+                np.testing.assert_array_equal(pull(w, OBS)[~fin, 0], orc.obs[~fin])
+            finished += int((orc.done > 0).sum())
+            orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state, err_msg=f"launch {launch}")
+        np.testing.assert_array_equal(pull(w, "_timestep_"), orc.timestep)
+    assert finished >= E
+
+
 def test_consistency_checker_api():
     """The reference's own parity harness, at 1e-5 instead of 1 % (its scenarios:
     tests/example_envs/pycuda_tests/test_tag_continuous.py:15-80, test_tag_gridworld.py:13-38)."""

@@ -119,3 +119,58 @@ def test_gridworld_ragged_sizes():
             _check_step(w, orc, tag=f"E={E} N={taggers + 1} t={t}")
             w.reset_only_done_envs()
             orc.reset_done_envs()
+
+
+@pytest.mark.parametrize("full_obs,E", [(True, 1000), (False, 77)])
+def test_gridworld_fused_tick(full_obs, E):
+    """HipTagGridWorldTick: sampling + step + in-kernel reset in ONE launch.  The sampled actions are
+    checked draw-for-draw against the CPU restatement of the kernel's Philox uniforms, then replayed
+    through the oracle; finished replicas must already be reset when the launch returns while
+    `_done_` still reports them."""
+    import torch
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from tests.hip_harness import OBS, REW, pull, ulp_diff
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    cfg = dict(num_taggers=4, grid_length=10, episode_length=23, seed=27, wall_hit_penalty=0.1,
+               tag_reward_for_tagger=10.0, tag_penalty_for_runner=2.0, step_cost_for_tagger=0.01,
+               use_full_observation=full_obs)
+    w = _mk(cfg, E)
+    N = w.n_agents
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=5)  # (placeholders were pushed by the harness)
+    rng = np.random.RandomState(3)
+    probs = torch.from_numpy(rng.dirichlet(np.ones(5), size=(E, N)).astype(np.float32)).cuda()
+    engine = RolloutEngine(w, sampler, probabilities=[probs])
+    assert engine.fused and engine.step_kernel_name == "HipTagGridWorldTick" and len(engine.entry_names) == 1
+    ocfg = dict(cfg)
+    ocfg.pop("seed")
+    orc = TagGridWorldOracle(num_envs=E, **ocfg)
+    rng_words = np.zeros(4 + E * N, dtype=np.uint32)
+    probs_host = probs.cpu().numpy()
+    finished = 0
+    for t in range(60):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        engine.run(1)
+        torch.cuda.synchronize()
+        a = pull(w, "sampled_actions")[..., 0]
+        u, _ = fused_tick_uniforms(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
+        np.testing.assert_array_equal(a, sample_actions_counting(probs_host, u.reshape(E, N)), err_msg=f"t={t}")
+        orc.step(a)
+        np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")   # still set
+        assert ulp_diff(pull(w, REW), orc.rewards.astype(np.float32)).max() <= 1
+        fin = orc.done > 0
+        finished += int(fin.sum())
+        obs_step = orc.obs.astype(np.float32).copy()
+        orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "loc_x"), orc.loc_x, err_msg=f"t={t}")
+        np.testing.assert_array_equal(pull(w, "loc_y"), orc.loc_y, err_msg=f"t={t}")
+        np.testing.assert_array_equal(pull(w, "_timestep_"), orc.timestep, err_msg=f"t={t}")
+        obs_dev = pull(w, OBS)
+        np.testing.assert_array_equal(obs_dev[~fin], obs_step[~fin], err_msg=f"t={t}")
+        np.testing.assert_array_equal(obs_dev[fin], orc.obs.astype(np.float32)[fin], err_msg=f"t={t}")
+    assert finished >= 2 * E

@@ -14,37 +14,121 @@
 // E = 100 000 moves 6.8 MB -- under 1 us of HBM time, i.e. launch-bound).
 #include "wd_common.h"
 
-extern "C" __global__ void HipClassicControlCartPoleEnvStep(
+namespace {
+
+struct CpPhysics {
+  float gravity, masspole, total_mass, length, polemass_length, force_mag, tau;
+  float theta_threshold_radians, x_threshold;
+};
+
+// one Euler update, cartpole_step_numba.py:42-78 (float32 state; everything downstream of the
+// Python literal 4.0/3.0 in float64, as Numba types it)
+__device__ __forceinline__ bool cp_euler(float4 &s, int action, const CpPhysics &p) {
+  float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
+  const float force = (action > 0) ? p.force_mag : -p.force_mag;  // action > 0.5
+  float sintheta, costheta;
+  wd_np_sincosf(theta, sintheta, costheta);
+  const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) / p.total_mass;
+  const double den = (double)p.length * (4.0 / 3.0 - (double)(p.masspole * (costheta * costheta) / p.total_mass));
+  const double thetaacc = (double)(p.gravity * sintheta - costheta * temp) / den;
+  const double xacc = (double)temp - (double)p.polemass_length * thetaacc * (double)costheta / (double)p.total_mass;
+  x = x + p.tau * x_dot;
+  x_dot = (float)((double)x_dot + (double)p.tau * xacc);
+  theta = theta + p.tau * theta_dot;
+  theta_dot = (float)((double)theta_dot + (double)p.tau * thetaacc);
+  s = make_float4(x, x_dot, theta, theta_dot);
+  return x < -p.x_threshold || x > p.x_threshold || theta < -p.theta_threshold_radians ||
+         theta > p.theta_threshold_radians;
+}
+
+struct CpResetEntry {  // same layout as wd_reset_entry in wd_core.hip
+  uint32_t *data;
+  const uint32_t *ref;
+  int row_elems;
+  int pad_;
+};
+
+}  // namespace
+
+extern "C" {
+
+__global__ void HipClassicControlCartPoleEnvStep(
     float4 *__restrict__ state_arr, const int *__restrict__ action_arr, int *__restrict__ done_arr,
     float *__restrict__ reward_arr, float4 *__restrict__ observation_arr, float gravity,
     float masspole, float total_mass, float length, float polemass_length, float force_mag,
     float tau, float theta_threshold_radians, float x_threshold,
     int *__restrict__ env_timestep_arr, int episode_length, int n_envs) {
-  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs;
-       env += gridDim.x * blockDim.x) {
+  const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
+                    theta_threshold_radians, x_threshold};
+  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
     const int t = env_timestep_arr[env] + 1;
     env_timestep_arr[env] = t;
-    const float4 s = state_arr[env];
-    float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
-    const float force = (action_arr[env] > 0) ? force_mag : -force_mag;  // action > 0.5
-    float sintheta, costheta;
-    wd_np_sincosf(theta, sintheta, costheta);
-    const float temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
-    const double den = (double)length *
-                       (4.0 / 3.0 - (double)(masspole * (costheta * costheta) / total_mass));
-    const double thetaacc = (double)(gravity * sintheta - costheta * temp) / den;
-    const double xacc =
-        (double)temp - (double)polemass_length * thetaacc * (double)costheta / (double)total_mass;
-    x = x + tau * x_dot;
-    x_dot = (float)((double)x_dot + (double)tau * xacc);
-    theta = theta + tau * theta_dot;
-    theta_dot = (float)((double)theta_dot + (double)tau * thetaacc);
-    const float4 o = make_float4(x, x_dot, theta, theta_dot);
-    state_arr[env] = o;
-    observation_arr[env] = o;
-    const bool terminated = x < -x_threshold || x > x_threshold ||
-                            theta < -theta_threshold_radians || theta > theta_threshold_radians;
+    float4 s = state_arr[env];
+    const bool terminated = cp_euler(s, action_arr[env], p);
+    state_arr[env] = s;
+    observation_arr[env] = s;
     reward_arr[env] = 1.0f;
     if (t == episode_length || terminated) done_arr[env] = 1;
   }
 }
+
+// Fused rollout tick(s): sample the action + step + reset a finished replica, `ticks` times per launch
+// with the state kept in registers (a single tick at E = 100 000 moves 6.8 MB: under 1 us of HBM time,
+// so one launch per tick is launch-bound -- SURVEY 8(d) asks the ceiling run to fuse T ticks).  The
+// policy's probabilities are read once per launch, so ticks > 1 is a fixed-policy rollout; every tick
+// still writes its action, observation, reward, done and timestep.  `_done_` reports the last tick.
+// (No __restrict__ on the arrays: the reset table aliases them.)
+__global__ void HipClassicControlCartPoleEnvTick(
+    float4 *state_arr, int *action_arr, int *done_arr,
+    float *reward_arr, float4 *observation_arr, float gravity,
+    float masspole, float total_mass, float length, float polemass_length, float force_mag,
+    float tau, float theta_threshold_radians, float x_threshold,
+    int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
+    const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
+    int stream_tag, int ticks) {
+  const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
+                    theta_threshold_radians, x_threshold};
+  const CpResetEntry *table = (const CpResetEntry *)reset_table;
+  const uint32_t k0 = rng_state[0], k1 = rng_state[1];
+  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
+    int t = env_timestep_arr[env];
+    float4 s = state_arr[env];
+    const uint32_t epoch0 = rng_state[WD_RNG_HEADER + env];
+    const float *row = probs + (long)env * n_actions;
+    for (int k = 0; k < ticks; ++k) {
+      // ---- sample (random.cu:51-85): inverse CDF on a running float32 sum
+      const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, 3u}, k0, k1);
+      const float u = wd_u01_open_closed(rnd.x);
+      float cum = 0.0f;
+      int cnt = 0;
+      for (int i = 0; i < n_actions; ++i) {
+        cum = (i == 0) ? row[0] : cum + row[i];
+        cnt += (cum < u) ? 1 : 0;
+      }
+      const int a = min(cnt, n_actions - 1);
+      // ---- step
+      t += 1;
+      const bool terminated = cp_euler(s, a, p);
+      const bool fin = (t == episode_length) || terminated;
+      action_arr[env] = a;
+      observation_arr[env] = s;
+      reward_arr[env] = 1.0f;
+      done_arr[env] = fin ? 1 : 0;
+      state_arr[env] = s;
+      // ---- reset in place (reset.cu:9-75 for every registered array); `_done_` stays set
+      if (fin) {
+        for (int r = 0; r < n_reset_arrays; ++r) {
+          const CpResetEntry ent = table[r];
+          const long base = (long)env * ent.row_elems;
+          for (int i = 0; i < ent.row_elems; ++i) ent.data[base + i] = ent.ref[base + i];
+        }
+        t = 0;
+        s = state_arr[env];
+      }
+    }
+    env_timestep_arr[env] = t;
+    rng_state[WD_RNG_HEADER + env] = epoch0 + (uint32_t)ticks;
+  }
+}
+
+}  // extern "C"

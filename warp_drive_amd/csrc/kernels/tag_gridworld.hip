@@ -8,11 +8,10 @@
 // MI355X mapping.  A replica has only N = num_taggers + 1 agents (5 in every
 // BASELINE config), so block-per-env would light 5 of 64 lanes.  Instead a block
 // packs epb = blockDim.x / N replicas (12 per wavefront at N = 5): thread t serves
-// agent t % N of local replica t / N.  Positions are staged in LDS; the observation
-// block of the packed replicas is contiguous in HBM ([E, N, F] row-major) and is
-// written with block-strided, fully coalesced stores instead of one strided row per
-// thread (tag_gridworld_step_pycuda.cu:29-51).  With the reference geometry
-// (block=(N,1,1), grid=(E,1)) epb is simply 1.
+// agent t % N of local replica t / N.  Positions are staged in LDS; each thread builds
+// its agent's observation row in an LDS image of the block's slice, which is contiguous
+// in HBM ([E, N, F] row-major) and leaves with flat, fully coalesced stores.  With the
+// reference geometry (block=(N,1,1), grid=(E,1)) epb is simply 1.
 #include "wd_common.h"
 
 // action index -> (dx, dy); uploaded by the host like the reference
@@ -20,23 +19,76 @@
 // and pre-initialised to TagGridWorld.step_actions (tag_gridworld.py:104).
 __constant__ int kIndexToActionArr[10] = {0, 0, 1, 0, -1, 0, 0, 1, 0, -1};
 
-extern "C" __global__ void HipTagGridWorldStep(
-    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr,
-    const int *__restrict__ actions_arr, int *__restrict__ done_arr,
-    float *__restrict__ rewards_arr, float *__restrict__ obs_arr, float wall_hit_penalty,
-    float tag_reward_for_tagger, float tag_penalty_for_runner, float step_cost_for_tagger,
-    int use_full_observation, int world_boundary, int *__restrict__ env_timestep_arr,
-    int episode_length, int n_agents, int n_envs) {
-  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+#define WD_GW_IMAGE_MAX_BYTES 60000  // dynamic LDS budget of one block (default limit 64 KB)
+
+namespace {
+
+struct GwResetEntry {  // same layout as wd_reset_entry in wd_core.hip
+  uint32_t *data;
+  const uint32_t *ref;
+  int row_elems;
+  int pad_;
+};
+
+struct GwFuse {
+  uint32_t *rng_state;       // Philox epoch counters (WD_RNG_HEADER + one word per agent row)
+  const float *probs;        // [E, N, n_actions] policy output
+  int n_actions;
+  const GwResetEntry *reset_table;
+  int n_reset_arrays;
+  int stream_tag;
+};
+
+// one agent's observation row, tag_gridworld.py:194-275
+__device__ __forceinline__ void gw_write_row(float *row, const float *fx, const float *fy, int N, int ag, int best,
+                                             float tnorm, int use_full_observation) {
+  if (use_full_observation) {
+    for (int j = 0; j < N; ++j) {
+      row[j] = fx[j];
+      row[N + j] = fy[j];
+      row[2 * N + j] = (j == N - 1) ? 1.0f : 0.0f;
+      row[3 * N + j] = (j == ag) ? 1.0f : 0.0f;
+    }
+    row[4 * N] = tnorm;
+  } else {
+    const int other = (ag < N - 1) ? N - 1 : best;
+    row[0] = fx[ag];
+    row[1] = fy[ag];
+    row[2] = fx[other];
+    row[3] = fy[other];
+    row[4] = (ag == N - 1) ? 1.0f : 0.0f;
+    row[5] = tnorm;
+  }
+}
+
+// One trip = epb packed replicas.  Thread t serves agent t % N of local replica t / N and writes that
+// agent's whole observation row into an LDS image of the block's [epb*N, F] slice; the image is then
+// copied out flat (consecutive lanes -> consecutive floats), so the obs stores are fully coalesced
+// and no index arithmetic (the reference decodes (agent, feature) from a flat index with integer
+// divisions, tag_gridworld_step_pycuda.cu:29-51) is left in the copy loop.
+template <bool FUSED>
+__device__ __forceinline__ void gw_step_impl(
+    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
+    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
+    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs, const GwFuse &fz,
+    int *s_mem) {
   const int N = n_agents;
   const int epb = max(1, (int)blockDim.x / N);  // replicas per block
-  int *s_x = s_mem;                             // [epb][N]
-  int *s_y = s_x + epb * N;                     // [epb][N]
-  int *s_t = s_y + epb * N;                     // [epb] timestep after increment
-  int *s_tag = s_t + epb;                       // [epb] runner caught?
-  int *s_near = s_tag + epb;                    // [epb] closest tagger (partial obs)
+  const int A = epb * N;
   const int F = use_full_observation ? 4 * N + 1 : 6;
-  const int tid = threadIdx.x;
+  int *s_x = s_mem;                             // [A] positions after the move
+  int *s_y = s_x + A;                           // [A]
+  float *s_fx = (float *)(s_y + A);             // [A] x / L  (float32 division, :208-214)
+  float *s_fy = s_fx + A;                       // [A]
+  int *s_t = (int *)(s_fy + A);                 // [epb] timestep after increment
+  int *s_done = s_t + epb;                      // [epb] replica finished on this tick
+  float *s_obs = (float *)(s_done + epb);       // [A][F] image of the block's observation slice
+  // very wide rows (N ~ 64 with full observations) do not fit an LDS image: those blocks write their
+  // rows straight to HBM.  The host sizes the dynamic LDS with the same rule (lds_bytes()).
+  const bool image = (size_t)4 * ((size_t)4 * A + 2 * epb + (size_t)A * F) <= WD_GW_IMAGE_MAX_BYTES;
+  const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const float L = (float)world_boundary;
 
@@ -44,10 +96,31 @@ extern "C" __global__ void HipTagGridWorldStep(
     const int env = env0 + el;
     const bool active = (el < epb) && (env < n_envs);
     const int idx = env * N + ag;
+    const int li = el * N + ag;
     float rew = 0.0f;
     if (active) {
+      int a;
+      if (FUSED) {
+        // ---- sample the action (random.cu:51-85): inverse CDF on a running float32 sum
+        if (ag == 0) done_arr[env] = 0;  // a replica that finished (and was reset) last tick
+        const uint32_t epoch = fz.rng_state[WD_RNG_HEADER + idx];
+        fz.rng_state[WD_RNG_HEADER + idx] = epoch + 1u;
+        const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)idx, epoch, (uint32_t)fz.stream_tag, 3u},
+                                           fz.rng_state[0], fz.rng_state[1]);
+        const float u = wd_u01_open_closed(rnd.x);
+        const float *row = fz.probs + (long)idx * fz.n_actions;
+        float cum = 0.0f;
+        int cnt = 0;
+        for (int i = 0; i < fz.n_actions; ++i) {
+          cum = (i == 0) ? row[0] : cum + row[i];
+          cnt += (cum < u) ? 1 : 0;
+        }
+        a = min(cnt, fz.n_actions - 1);
+        actions_arr[idx] = a;
+      } else {
+        a = actions_arr[idx];
+      }
       // ---- movement :152-173
-      const int a = actions_arr[idx];
       const int ux = states_x_arr[idx] + kIndexToActionArr[2 * a];
       const int uy = states_y_arr[idx] + kIndexToActionArr[2 * a + 1];
       const int cx = min(max(ux, 0), world_boundary);
@@ -55,8 +128,10 @@ extern "C" __global__ void HipTagGridWorldStep(
       if (ux != cx || uy != cy) rew = -wall_hit_penalty;  // -1.0 * wall_hit_penalty * hit
       states_x_arr[idx] = cx;
       states_y_arr[idx] = cy;
-      s_x[el * N + ag] = cx;
-      s_y[el * N + ag] = cy;
+      s_x[li] = cx;
+      s_y[li] = cy;
+      s_fx[li] = (float)cx / L;
+      s_fy[li] = (float)cy / L;
       if (ag == 0) {
         const int t = env_timestep_arr[env] + 1;  // :295
         env_timestep_arr[env] = t;
@@ -64,55 +139,94 @@ extern "C" __global__ void HipTagGridWorldStep(
       }
     }
     __syncthreads();
-    if (active && ag == 0) {
-      // ---- tag check :175-178 and closest tagger :246-261 (first argmin)
-      const int rx = s_x[el * N + N - 1], ry = s_y[el * N + N - 1];
+    if (active) {
+      // ---- tag check :175-178 and closest tagger :246-261 (first argmin); every agent of the replica
+      // evaluates the N-1 taggers itself (LDS broadcasts) instead of waiting for one thread
+      const int *x = s_x + el * N, *y = s_y + el * N;
+      const int rx = x[N - 1], ry = y[N - 1];
       int tag = 0, best = 0, bd = 0x7fffffff;
       for (int j = 0; j < N - 1; ++j) {
-        const int dx = s_x[el * N + j] - rx, dy = s_y[el * N + j] - ry;
+        const int dx = x[j] - rx, dy = y[j] - ry;
         const int d = dx * dx + dy * dy;
         tag |= (d == 0);
         if (d < bd) { bd = d; best = j; }
       }
-      s_tag[el] = tag;
-      s_near[el] = best;
-      if (s_t[el] >= episode_length || tag) done_arr[env] = 1;  // :314
-    }
-    __syncthreads();
-    if (active) {
+      const int t = s_t[el];
+      if (ag == 0) {
+        const bool fin = (t >= episode_length) || tag;  // :314
+        if (fin) done_arr[env] = 1;
+        s_done[el] = fin ? 1 : 0;
+      }
       // ---- rewards :180-187
-      const int tag = s_tag[el];
       const float base = (ag < N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
                                       : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
       rewards_arr[idx] = base + rew;
+      // ---- this agent's observation row :194-275
+      const float tnorm = (float)t / (float)episode_length;
+      // (two calls, so the LDS image and the HBM row keep their own address spaces -- a pointer
+      // that may be either becomes a flat access)
+      if (image) gw_write_row(s_obs + (size_t)li * F, s_fx + el * N, s_fy + el * N, N, ag, best, tnorm, use_full_observation);
+      else gw_write_row(obs_arr + (long)idx * F, s_fx + el * N, s_fy + el * N, N, ag, best, tnorm, use_full_observation);
     }
-    // ---- observations :194-275, coalesced over the packed replicas
+    __syncthreads();
+    // ---- flat, coalesced copy of the observation image
     const int envs_here = min(epb, n_envs - env0);
-    const int per_env = N * F;
-    const long obs_base = (long)env0 * per_env;
-    for (int q = tid; q < envs_here * per_env; q += blockDim.x) {
-      const int e = q / per_env, r = q - e * per_env;
-      const int i = r / F, f = r - i * F;
-      const int *x = s_x + e * N, *y = s_y + e * N;
-      float v;
-      if (use_full_observation) {
-        const int c = f / N, j = f - c * N;
-        if (c == 0) v = (float)x[j] / L;
-        else if (c == 1) v = (float)y[j] / L;
-        else if (c == 2) v = (j == N - 1) ? 1.0f : 0.0f;
-        else if (c == 3) v = (j == i) ? 1.0f : 0.0f;
-        else v = (float)s_t[e] / (float)episode_length;
-      } else {
-        const int other = (i < N - 1) ? N - 1 : s_near[e];
-        if (f == 0) v = (float)x[i] / L;
-        else if (f == 1) v = (float)y[i] / L;
-        else if (f == 2) v = (float)x[other] / L;
-        else if (f == 3) v = (float)y[other] / L;
-        else if (f == 4) v = (i == N - 1) ? 1.0f : 0.0f;
-        else v = (float)s_t[e] / (float)episode_length;
+    const int n_out = envs_here * N * F;
+    float *dst = obs_arr + (long)env0 * N * F;
+    if (image)
+      for (int q = tid; q < n_out; q += T_) dst[q] = s_obs[q];
+    // ---- fused tick: restore finished replicas in place (reset.cu:9-75 for every registered array;
+    // `_done_` stays 1 for the trainer, the next tick clears it).  All writes of this block to these
+    // rows are ordered before the copies by the barrier.
+    if (FUSED) {
+      __syncthreads();
+      for (int e = 0; e < envs_here; ++e) {
+        if (s_done[e] == 0) continue;  // block-uniform
+        for (int r = 0; r < fz.n_reset_arrays; ++r) {
+          const GwResetEntry ent = fz.reset_table[r];
+          const long base = (long)(env0 + e) * ent.row_elems;
+          for (int i = tid; i < ent.row_elems; i += T_) ent.data[base + i] = ent.ref[base + i];
+        }
+        if (tid == 0) env_timestep_arr[env0 + e] = 0;
       }
-      obs_arr[obs_base + q] = v;
     }
     __syncthreads();
   }
 }
+
+}  // namespace
+
+extern "C" {
+
+__global__ void HipTagGridWorldStep(
+    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
+    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
+    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs) {
+  extern __shared__ __attribute__((aligned(16))) int gw_smem[];
+  gw_step_impl<false>(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
+                      tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger, use_full_observation,
+                      world_boundary, env_timestep_arr, episode_length, n_agents, n_envs, GwFuse{}, gw_smem);
+}
+
+// Fused rollout tick: sample the action + step + reset finished replicas in ONE launch (the reference
+// needs the sampler launch, the step, and one reset launch per registered array, trainer_base.py:392-426).
+__global__ void HipTagGridWorldTick(
+    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
+    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
+    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
+    const float *probs, int n_actions, const void *reset_table, int n_reset_arrays, int stream_tag) {
+  extern __shared__ __attribute__((aligned(16))) int gw_smem[];
+  GwFuse fz;
+  fz.rng_state = rng_state; fz.probs = probs; fz.n_actions = n_actions;
+  fz.reset_table = (const GwResetEntry *)reset_table; fz.n_reset_arrays = n_reset_arrays;
+  fz.stream_tag = stream_tag;
+  gw_step_impl<true>(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
+                     tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger, use_full_observation,
+                     world_boundary, env_timestep_arr, episode_length, n_agents, n_envs, fz, gw_smem);
+}
+
+}  // extern "C"

@@ -133,6 +133,25 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
         grid = (max(1, min(4096, (n_envs + 255) // 256)), 1)
         return self.cuda_step, self.cuda_step_function_feed(self._STEP_ARGS), block, grid, 0
 
+    TICK_HEADS = 1          # action heads the fused tick kernel samples (RolloutEngine)
+    ticks_per_launch = 1    # > 1: fixed-policy rollout, T ticks fused per launch (the HBM-ceiling run)
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None):
+        """Fused rollout tick(s): sample + step + reset of a finished replica, `ticks_per_launch`
+        times in ONE launch (HipClassicControlCartPoleEnvTick).  probabilities = [float32 CUDA tensor
+        [E, 1, n_actions]]; `_done_` reports the last tick of the launch."""
+        from warp_drive_amd.managers.function_manager import _stream_tag
+
+        assert env_range is None and len(probabilities) == 1
+        fm, dm = self.cuda_function_manager, self.cuda_data_manager
+        name = self.cuda_step.name.replace("Step", "Tick")
+        fm.initialize_functions([name])
+        _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
+        _, args, block, grid, _ = self.step_launch()
+        args = list(args) + [sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0],
+                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)]
+        return fm.get_function(name), args, block, grid, 0
+
     def step(self, actions=None):
         self.timestep += 1
         if self.env_backend != "hip":

@@ -136,6 +136,8 @@ _STEP_ARGS = [
 class _DeviceStepMixin(CUDAEnvironmentContext):
     """Device step: one launch of HipTagGridWorldStep over all replicas."""
 
+    TICK_HEADS = 1  # action heads the fused tick kernel samples (RolloutEngine)
+
     def _scalar_feed(self):
         return [
             ("wall_hit_penalty", self.wall_hit_penalty),
@@ -146,12 +148,48 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
             ("world_boundary", self.grid_length),
         ]
 
-    def step_launch(self):
-        """(function, args, block, grid, shared_bytes) of one device tick."""
+    def _geometry(self):
+        """Blocks pack whole replicas (the kernels derive replicas-per-block from blockDim).  Small
+        batches get small blocks so that the launch still spreads over the chip (1000 replicas of 5
+        agents: 84 single-wavefront blocks instead of 20 blocks of 256 threads)."""
         fm = self.cuda_function_manager
-        epb, block, grid = fm.packed_geometry(self.num_agents, max_threads=256)
-        shared = 4 * (2 * epb * self.num_agents + 3 * epb)
-        return self.cuda_step, self.cuda_step_function_feed(_STEP_ARGS), block, grid, shared
+        choice = None
+        for max_threads in (256, 128, 64):
+            choice = fm.packed_geometry(self.num_agents, max_threads=max(max_threads, self.num_agents))
+            if choice[2][0] >= 512:
+                break
+        return choice
+
+    def lds_bytes(self, epb):
+        """dynamic LDS of HipTagGridWorldStep / Tick: positions (int + normalised float), per-replica
+        timestep / done, and the [epb * N, F] observation image"""
+        A = epb * self.num_agents
+        F = 4 * self.num_agents + 1 if self.use_full_observation else 6
+        with_image = 4 * (4 * A + 2 * epb + A * F)
+        return with_image if with_image <= 60000 else 4 * (4 * A + 2 * epb)  # WD_GW_IMAGE_MAX_BYTES
+
+    def step_launch(self):
+        """(function, args, block, grid, shared_bytes) of one device step."""
+        epb, block, grid = self._geometry()
+        return self.cuda_step, self.cuda_step_function_feed(_STEP_ARGS), block, grid, self.lds_bytes(epb)
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None):
+        """Fused rollout tick: sample the action + step + reset finished replicas in ONE launch
+        (HipTagGridWorldTick).  probabilities = [float32 CUDA tensor [E, N, n_actions]].  `_done_`
+        stays set for replicas that finished on the tick (already reset); the next tick clears it."""
+        from warp_drive_amd.managers.function_manager import _stream_tag
+
+        assert env_range is None, "replica ranges are a TagContinuous experiment"
+        assert len(probabilities) == 1
+        fm, dm = self.cuda_function_manager, self.cuda_data_manager
+        name = self.cuda_step.name.replace("Step", "Tick")
+        fm.initialize_functions([name])
+        _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
+        epb, block, grid = self._geometry()
+        args = list(self.cuda_step_function_feed(_STEP_ARGS)) + [
+            sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0], reset_args[1],
+            _stream_tag("tick")]
+        return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
 
     def step(self, actions=None):
         self.timestep += 1

@@ -57,8 +57,14 @@ class RolloutEngine:
         H = len(head_sizes)
         self.entry_names = []
         self._graph_ticks = 0
-        self.fused = bool(fused and reset_done and hasattr(env_wrapper.env, "tick_launch") and H == 2)
+        # an env class that offers tick_launch() fuses sampling, step and reset in its own kernel
+        # (restarts from a reset pool draw random members: that stays with the pool reset kernel)
+        self.fused = bool(fused and reset_done and hasattr(env_wrapper.env, "tick_launch")
+                          and H == getattr(env_wrapper.env, "TICK_HEADS", 2)
+                          and len(dm.reset_target_to_pool) == 0)
         self.group_plans, self.group_streams = [], []
+        # env ticks per launch (> 1 only for envs whose fused kernel loops over ticks, fixed policy)
+        self.ticks_per_launch = int(getattr(env_wrapper.env, "ticks_per_launch", 1)) if self.fused else 1
         if self.fused:
             # whole tick = ONE launch: sampling, step and reset fused in the env's tick kernel
             fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
