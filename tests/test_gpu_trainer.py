@@ -48,7 +48,12 @@ def test_train_gridworld_and_cartpole(tmp_path):
     ov = {"trainer": {"num_envs": 50, "train_batch_size": 50 * 25, "num_episodes": 2},
           "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
     trainer, metrics = _train("tag_gridworld", ov, tmp_path / "gw")
-    assert not trainer.engine.fused and set(metrics) == {"runner", "tagger"}
+    assert trainer.engine.fused and set(metrics) == {"runner", "tagger"}
+    # the same through separate sampler / step / reset launches (envs without a tick kernel)
+    ov["trainer"]["fused_rollout"] = False
+    trainer, metrics = _train("tag_gridworld", ov, tmp_path / "gw_unfused")
+    assert not trainer.engine.fused and len(trainer.engine.entry_names) >= 2
+    ov["trainer"].pop("fused_rollout")
     ov["policy"] = {"runner": {"algorithm": "PPO", "to_train": True, "lr": 0.01, "vf_loss_coeff": 1,
                                "model": {"fc_dims": [32]}},
                     "tagger": {"algorithm": "PPO", "to_train": True, "lr": 0.01, "vf_loss_coeff": 1,

@@ -118,7 +118,8 @@ class Trainer:
         N = env_wrapper.n_agents
         # policy output lives in fixed tensors the tick kernel reads in place
         self.probs = [torch.full((E, N, a), 1.0 / a, dtype=torch.float32, device=self.device) for a in self.head_sizes]
-        self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True)
+        self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
+                                    fused=bool(self.config["trainer"].get("fused_rollout", True)))
         if not self.engine.fused:
             # envs without a fused tick kernel: the reset launch clears `_done_`, so it runs after the
             # flags were copied into the batch (still device-side, no host sync)
