@@ -114,3 +114,19 @@ def test_ddp_gradient_allreduce_two_ranks(tmp_path):
     mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     w0, w1 = np.load(tmp_path / "w_0.npy"), np.load(tmp_path / "w_1.npy")
     np.testing.assert_array_equal(w0, w1)  # different data, identical parameters after the step
+
+
+def test_launcher_command_line(capsys):
+    """f2: the launcher starts one rank per GPU through torch.distributed.run on localhost"""
+    from warp_drive_amd.training.scripts import launch
+
+    cmd = launch.build_command("tag_continuous", 8, 29512, ["--iters", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-5:] == ["warp_drive_amd.training.scripts.train", "--env", "tag_continuous", "--iters", "3"]
+    assert launch.child_environment({})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launch.main(["--env", "tag_gridworld", "--num_gpus", "2", "--dry_run", "--iters", "1"]) == 0
+    out = capsys.readouterr().out
+    assert "--nproc-per-node=2" in out and out.strip().endswith("--env tag_gridworld --iters 1")
+    port = launch.free_port()
+    assert 1024 < port < 65536
