@@ -102,8 +102,11 @@ int wd_plan_instantiate_graph(void *plan, int repeats_per_graph, void *stream);
 int wd_plan_run_graph(void *plan, int graph_launches, void *stream);
 /* sample the device duration of entry `entry_index` with HIP events recorded on the
  * launch stream around that launch, every `sample_stride`-th repetition of wd_plan_run
- * (at most max_samples pairs are kept; -1 disables).  wd_plan_read_timing synchronises
- * the recorded events and returns the summed milliseconds and the number of samples. */
+ * (at most max_samples pairs are kept; -1 disables).  A plan that consists of one launch is
+ * bracketed over min(sample_stride, 8) consecutive repetitions per event pair, so the event
+ * cost is amortised and the result is the average launch duration of back-to-back launches.
+ * wd_plan_read_timing synchronises the recorded events and returns the summed milliseconds
+ * and the number of launches they cover. */
 int wd_plan_enable_timing(void *plan, int entry_index, int sample_stride, int max_samples);
 int wd_plan_read_timing(void *plan, float *total_ms, int *n_samples);
 int wd_plan_destroy(void *plan);

@@ -43,7 +43,7 @@ for fused in (True, False):
     torch.cuda.synchronize()
     print(f"=== ablate={ablate}: wall per tick {(time.perf_counter() - t0) / 2000 * 1e6:.2f} us")
     raw = w.cuda_data_manager.pull_data_from_device("neighbor_distances").view(np.uint64).reshape(-1, 16)
-    n_blocks = 1000
+    n_blocks = engine.plan_grid if hasattr(engine, 'plan_grid') else 2000
     st = raw[:n_blocks].astype(np.int64)
     names = {0: "start", 1: "prologue done", 2: "sampling done", 3: "move (P0) done", 4: "knn A done",
              5: "knn B done", 6: "knn C done", 7: "barrier after knn", 9: "obs gather issued", 10: "rewards done"}
@@ -59,6 +59,14 @@ for fused in (True, False):
     print(f"block lifetime: {real.mean()/1000:.2f} us wall = {(st[:, 10] - st[:, 0]).mean():.0f} shader cycles"
           f" -> shader clock {(st[:, 10] - st[:, 0]).mean() / real.mean():.3f} GHz;"
           f" first start -> last end {(st[:, 12].max() - st[:, 11].min()) / 100.0:.2f} us")
+    life = (st[:, 12] - st[:, 11]) / 100.0
+    start = (st[:, 11] - st[:, 11].min()) / 100.0
+    end = (st[:, 12] - st[:, 11].min()) / 100.0
+    pc = lambda a: " ".join(f"{np.percentile(a, q):6.2f}" for q in (0, 10, 50, 90, 99, 100))
+    print("percentiles 0/10/50/90/99/100 (us): lifetime", pc(life), "| start", pc(start), "| end", pc(end))
+    print("mean lifetime by blockIdx % 8 (XCD):", " ".join(f"{life[i::8].mean():.2f}" for i in range(8)))
+    print("mean lifetime by blockIdx quartile:", " ".join(f"{life[q * len(life) // 4:(q + 1) * len(life) // 4].mean():.2f}" for q in range(4)))
+    print("mean start by blockIdx quartile:", " ".join(f"{start[q * len(life) // 4:(q + 1) * len(life) // 4].mean():.2f}" for q in range(4)))
     tot = st[:, 10] - st[:, 0]
     print(f"{'total':<22} mean={tot.mean():10.0f}   spread of block start = {st[:,0].max()-st[:,0].min()}")
 
@@ -67,8 +75,8 @@ engine = RolloutEngine(w, sampler, fused=True, n_groups=2)
 engine.run(50)
 torch.cuda.synchronize()
 raw = w.cuda_data_manager.pull_data_from_device("neighbor_distances").view(np.uint64).reshape(-1, 16)
-st = raw[:1000].astype(np.int64)
+st = raw[:2000].astype(np.int64)   # 128-thread blocks: one replica per block, group g = rows [1000 g, 1000 (g + 1))
 t0 = st[:, 11].min()
-for g, sl in enumerate((slice(0, 500), slice(500, 1000))):
+for g, sl in enumerate((slice(0, 1000), slice(1000, 2000))):
     print(f"group {g}: last tick blocks start {(st[sl, 11].min() - t0) / 100.0:8.2f} us .. end {(st[sl, 12].max() - t0) / 100.0:8.2f} us "
           f"(mean block lifetime {((st[sl, 12] - st[sl, 11]).mean()) / 100.0:.2f} us)")
