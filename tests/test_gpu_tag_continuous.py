@@ -271,3 +271,74 @@ def test_fused_tick_kernel(full_obs):
     for c, p in zip(counts, probs):
         expected = p.cpu().numpy().reshape(-1, c.size).sum(0) * 40
         assert np.abs(c - expected).max() < 6 * np.sqrt(expected.max())
+
+
+def _push_state(w, **arrays):
+    """overwrite device state arrays in place (any registered array, torch-accessible or not)"""
+    import torch
+    from warp_drive_amd.managers import hip_driver as drv
+
+    dm = w.cuda_data_manager
+    for name, v in arrays.items():
+        v = np.ascontiguousarray(v, dtype=dm.get_dtype(name)).reshape(dm.get_shape(name))
+        if dm.is_data_on_device_via_torch(name):
+            dm.data_on_device_via_torch(name).copy_(torch.from_numpy(v))
+        else:
+            drv.memcpy_htod(dm.device_data(name), v)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 7])
+def test_exact_and_sqrt_ties_at_the_cut(K):
+    """Crafted positions: a lattice (many exactly equal distances, so the K-th nearest is tied with
+    others and the reference's stable id order decides, tag_continuous.py:435-437) plus a pair whose
+    squared distances to agent 0 differ by one ulp while their float32 sqrt is identical -- there the
+    reference prefers the LOWER id although its squared distance is the larger one.  Agents do not
+    move (zero acceleration / turn at zero speed), so every tick repeats the ties.  No near-tie
+    allowance: these must match exactly."""
+    from tests.hip_harness import OBS, pull, push_actions
+
+    cfg = dict(num_taggers=2, num_runners=10, grid_length=20.0, episode_length=9, seed=1, max_acceleration=0.1,
+               min_acceleration=-0.1, num_acceleration_levels=4, num_turn_levels=4, use_full_observation=False,
+               num_other_agents_observed=K, tagging_distance=1e-5, runner_exits_game_after_tagged=True)
+    E = 5
+    w = _mk(cfg, E)
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    N = orc.N
+    # agent 0 at (5,5); agent 1 at (6, 5.0003): d2 = 1 + 2^-23, sqrt -> 1.0; agent 2 at (6,5): d2 = 1, sqrt = 1.0
+    xs = np.array([5, 6, 6, 4, 5, 5, 7, 3, 6, 4, 9, 9], dtype=np.float32)
+    ys = np.array([5, 5.0003, 5, 5, 6, 4, 5, 5, 6, 4, 9, 10], dtype=np.float32)
+    assert len(xs) == N
+    d2_a = np.float32((xs[1] - xs[0]) ** 2) + np.float32((ys[1] - ys[0]) * (ys[1] - ys[0]))
+    assert np.float32(d2_a) > np.float32(1.0) and np.sqrt(np.float32(d2_a), dtype=np.float32) == np.float32(1.0)
+    state = dict(loc_x=np.tile(xs, (E, 1)), loc_y=np.tile(ys, (E, 1)), speed=np.zeros((E, N), np.float32),
+                 direction=np.zeros((E, N), np.float32), acceleration=np.zeros((E, N), np.float32))
+    orc.set_state(**state)
+    _push_state(w, **state)
+    a0 = int(np.argmin(np.abs(orc.acceleration_actions)))
+    t0 = int(np.argmin(np.abs(orc.turn_actions)))
+    assert orc.acceleration_actions[a0] == 0 and orc.turn_actions[t0] == 0
+    act = np.zeros((E, N, 2), dtype=np.int32)
+    act[..., 0], act[..., 1] = a0, t0
+    for t in range(4):
+        push_actions(w, act)
+        w.step_all_envs()
+        orc.step(act)
+        np.testing.assert_array_equal(pull(w, "loc_x"), orc.loc_x)
+        np.testing.assert_array_equal(pull(w, "loc_y"), orc.loc_y)
+        np.testing.assert_array_equal(pull(w, OBS), orc.obs.astype(np.float32), err_msg=f"K={K} t={t}")
+    if K == 1:  # the lower id wins the sqrt tie although it is farther in squared distance
+        ids = orc.knn()
+        assert ids[0, 0, 0] == 1
+
+
+@pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (525, 5, False), (1020, 3, False)])
+def test_many_agents_paths(n_runners, K, full_obs):
+    """replicas larger than the bit-mask path: 129..512 agents use the LDS candidate lists of the
+    register-resident search, more than 512 agents the generic entry point (one block of up to 1024
+    threads per replica)"""
+    cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=30.0, episode_length=6, seed=13,
+               max_acceleration=0.2, min_acceleration=-0.2, num_acceleration_levels=5, num_turn_levels=5,
+               use_full_observation=full_obs, num_other_agents_observed=K, tagging_distance=0.2,
+               runner_exits_game_after_tagged=True)
+    _run_lockstep(cfg, E=3, ticks=8, seed=n_runners)

@@ -830,7 +830,12 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
           if (acc == 123.456f) row[0] = acc;
         } else {
 #pragma unroll
-          for (int c = 0; c < 7; ++c) tc_store_obs(row + c * W + k, vals[c]);
+          for (int c = 0; c < 7; ++c) {
+            if (WD_TC_ABLATE & 128)  // timing experiment: same bytes, fully coalesced (wrong layout)
+              tc_store_obs(obs_blk + (long)c * items + t, vals[c]);
+            else
+              tc_store_obs(row + c * W + k, vals[c]);
+          }
         }
         // advance (m, i, k) by the block stride
         k += sk;
