@@ -26,11 +26,12 @@ def _train(env_name, overrides, tmp_path, iters=3):
 
 
 def test_train_tag_continuous(tmp_path):
-    ov = {"trainer": {"num_envs": 64, "train_batch_size": 64 * 20, "num_episodes": 2},
+    ov = {"trainer": {"num_envs": 64, "train_batch_size": 64 * 20, "num_episodes": 2, "graph_rollout": True},
           "env": {"num_runners": 20, "episode_length": 30, "num_other_agents_observed": 6},
           "saving": {"metrics_log_freq": 1, "model_params_save_freq": 2}}
     trainer, metrics = _train("tag_continuous", ov, tmp_path, iters=4)
     assert trainer.engine.fused  # the rollout is the single fused tick kernel
+    assert trainer._tick_graph is not None  # ... replayed, with the policy forward, from a hipGraph
     assert set(metrics) == {"runner", "tagger"}
     assert trainer.perf_stats.get_perf_stats()["Mean steps per sec (rollout)"] > 0
     ckpts = sorted(glob.glob(os.path.join(str(tmp_path), "*.state_dict")))
@@ -62,3 +63,36 @@ def test_train_gridworld_and_cartpole(tmp_path):
     ov2 = {"trainer": {"num_envs": 300, "train_batch_size": 300 * 30, "num_episodes": 1},
            "env": {"episode_length": 40}, "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
     _train("single_cartpole", ov2, tmp_path / "cp")
+
+
+def test_graph_and_eager_rollouts_agree(tmp_path):
+    """the hipGraph replay of a rollout tick must produce exactly what the eager tick produces"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.training.scripts.train import setup_trainer
+
+    require_gpu()
+    ov = {"trainer": {"num_envs": 32, "train_batch_size": 32 * 10, "num_episodes": 1, "seed": 7},
+          "env": {"num_runners": 12, "episode_length": 16, "num_other_agents_observed": 4},
+          "saving": {"metrics_log_freq": 100, "model_params_save_freq": 0}}
+    outs = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        ov["trainer"]["graph_rollout"] = graph
+        trainer = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"g{int(graph)}"), verbose=False)
+        if graph:  # the capture warm-up advances the environment by 3 ticks ...
+            trainer._generate_rollout_batch()
+            assert trainer._tick_graph is not None
+        else:      # ... so the eager run does the same 3 ticks first
+            for _ in range(3):
+                trainer._b_idx.zero_()
+                trainer._tick()
+            trainer._generate_rollout_batch()
+            assert trainer._tick_graph is None
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in (("obs", trainer.batch["runner"]["obs"]),
+                                               ("act", trainer.batch["runner"]["actions"]),
+                                               ("rew", trainer.batch["tagger"]["rewards"]),
+                                               ("done", trainer.done_batch))})
+        trainer.graceful_close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

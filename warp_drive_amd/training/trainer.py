@@ -168,37 +168,84 @@ class Trainer:
         self._ep_cnt = torch.zeros((), device=self.device)
         self.perf_stats = PerfStats()
         self.metrics = {}
+        # rollout tick as a hipGraph: needs a single-launch env tick (no Python-side branching)
+        self._b_idx = torch.zeros(1, dtype=torch.long, device=self.device)  # batch row of the current tick
+        self._tick_graph = None
+        self._want_graph = bool(tcfg.get("graph_rollout", False)) and self.engine.fused
 
     # --------------------------------------------------------------------------- rollout
+    def _inference_model(self, pol):
+        m = self.models[pol]
+        return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+
     @torch.no_grad()
+    def _tick(self):
+        """One rollout tick, entirely on the device and free of host-side indices: policy forward ->
+        fused env tick -> batch bookkeeping at row `self._b_idx` (a device counter), so the same
+        sequence of launches can be replayed from a hipGraph."""
+        b = self._b_idx
+        flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
+        for pol in self.policies:
+            ids = self.ids[pol]
+            obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
+            self.batch[pol]["obs"].index_copy_(0, b, obs_p.unsqueeze(0))
+            probs, _ = self._inference_model(pol)(obs_p)
+            for h, p in enumerate(probs):
+                if len(self.policies) == 1:
+                    self.probs[h].copy_(p)
+                else:
+                    self.probs[h].index_copy_(1, ids, p)
+        self.engine.run(1)  # sample + step (+ reset when fused), asynchronous on torch's stream
+        self.done_batch.index_copy_(0, b, self.done.unsqueeze(0))
+        if not self.engine.fused:
+            self.w.reset_only_done_envs()
+        finished = (self.done > 0).to(torch.float32)
+        for pol in self.policies:
+            ids = self.ids[pol]
+            a = self.actions if len(self.policies) == 1 else self.actions.index_select(1, ids)
+            r = self.rewards if len(self.policies) == 1 else self.rewards.index_select(1, ids)
+            self.batch[pol]["actions"].index_copy_(0, b, a.unsqueeze(0))
+            self.batch[pol]["rewards"].index_copy_(0, b, r.unsqueeze(0))
+            self._ep_reward[pol] += r
+            self._ep_sum[pol] += (self._ep_reward[pol].mean(dim=1) * finished).sum()
+            self._ep_reward[pol] *= (1.0 - finished)[:, None]
+        self._ep_cnt += finished.sum()
+        b += 1
+
+    def _capture_tick_graph(self):
+        """hipGraph of one tick (torch.cuda.CUDAGraph; the env kernel is launched through the C-ABI on
+        the capturing stream and is recorded like any other node).  A rollout is then `batch_len`
+        graph replays: one host call per tick instead of ~70 framework dispatches."""
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):   # allocator / library warm-up outside the capture
+                for _ in range(3):
+                    self._b_idx.zero_()
+                    self._tick()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            self._b_idx.zero_()
+            with torch.cuda.graph(graph):
+                self._tick()
+            torch.cuda.synchronize()
+            return graph
+        except Exception as err:  # capture is an optimisation: fall back to eager ticks, loudly
+            logging.warning(f"rollout tick could not be captured in a hipGraph ({err}); running it eagerly")
+            torch.cuda.synchronize()
+            return None
+
     def _generate_rollout_batch(self):
-        for b in range(self.batch_len):
-            flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
-            for pol in self.policies:
-                ids = self.ids[pol]
-                obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
-                self.batch[pol]["obs"][b].copy_(obs_p)
-                probs, _ = self.models[pol](obs_p)
-                for h, p in enumerate(probs):
-                    if len(self.policies) == 1:
-                        self.probs[h].copy_(p)
-                    else:
-                        self.probs[h].index_copy_(1, ids, p)
-            self.engine.run(1)  # sample + step (+ reset when fused), asynchronous on torch's stream
-            self.done_batch[b].copy_(self.done)
-            if not self.engine.fused:
-                self.w.reset_only_done_envs()
-            finished = (self.done > 0).to(torch.float32)
-            for pol in self.policies:
-                ids = self.ids[pol]
-                a = self.actions if len(self.policies) == 1 else self.actions.index_select(1, ids)
-                r = self.rewards if len(self.policies) == 1 else self.rewards.index_select(1, ids)
-                self.batch[pol]["actions"][b].copy_(a)
-                self.batch[pol]["rewards"][b].copy_(r)
-                self._ep_reward[pol] += r
-                self._ep_sum[pol] += (self._ep_reward[pol].mean(dim=1) * finished).sum()
-                self._ep_reward[pol] *= (1.0 - finished)[:, None]
-            self._ep_cnt += finished.sum()
+        if self._tick_graph is None and self._want_graph:
+            self._tick_graph = self._capture_tick_graph()
+            self._want_graph = self._tick_graph is not None
+        self._b_idx.zero_()
+        for _ in range(self.batch_len):
+            if self._tick_graph is not None:
+                self._tick_graph.replay()
+            else:
+                self._tick()
 
     # ---------------------------------------------------------------------------- update
     def _update_model_params(self, iteration, log):
