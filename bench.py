@@ -262,7 +262,7 @@ def main():
                 "samples": kern_n,
             },
         }
-        if not args.no_cpu_baseline and args.workload == "tag_continuous":
+        if not args.no_cpu_baseline and args.workload == "tag_continuous" and world == 1:  # N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline({k: v for k, v in cfg.items()})
             except Exception as err:  # the baseline is reported context, never a reason to lose the GPU number
