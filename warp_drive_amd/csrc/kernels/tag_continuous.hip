@@ -231,6 +231,7 @@ __device__ __forceinline__ void tc_copy_to_lds(float *dst, const float *__restri
 // `s_waitcnt vmcnt(0)` before the rows are read back (stride n dwords).  Producer and consumer are
 // the same wavefront: no block barrier.  A per-thread row walk instead costs 2n uncoalesced load
 // instructions per thread, each touching 64 rows (measured: 13 k of the tick's 74 k cycles).
+struct __attribute__((packed, aligned(4))) TcF4u { float x, y, z, w; };  // 16-byte access, dword aligned
 #define WD_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define WD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 __device__ __forceinline__ void tc_slab_fetch(float *dst, const float *__restrict__ src, int cnt, int lane) {
@@ -787,6 +788,44 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
       int k = tid % Wd, m = tid / Wd;         // block-local agent row and slot of the first item
       int i = m % N;                          // agent id inside its replica
       const int sk = T_ % Wd, sm = T_ / Wd, si = sm % N;
+      if (KMAX == 0 && a.use_full_obs && (W & 3) == 0 && W > 0 && !(WD_TC_ABLATE & (16 | 64 | 128))) {
+        // (generic entry points only: the host launches full observations through them, and the
+        // K-specialised kernels have no registers to spare)
+        // Full observations: rows are 7 runs of W consecutive floats, and the phase is bound by the
+        // number of store instructions (612 MB per tick at N = 105).  One work item = (row, four
+        // consecutive slots): 28 values, seven 16-byte stores (dword-aligned addresses) -- 4x fewer
+        // store instructions than one float per lane.
+        const int nq = W >> 2;
+        int q = tid % nq, mq = tid / nq, iq = mq % N;
+        const int sq = T_ % nq, smq = T_ / nq, siq = smq % N;
+        for (int t = tid; t < agents_here * nq; t += T_) {
+          const int ebase = mq - iq;
+          const bool in_game = l.sig[mq] != 0;
+          const TcFeat me = l.feat[mq];
+          float v[7][4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int kcol = 4 * q + kk;
+            const TcFeat nb = l.feat[ebase + kcol + (kcol >= iq ? 1 : 0)];
+            v[0][kk] = in_game ? (float)(nb.nx - me.nx) : 0.0f;
+            v[1][kk] = in_game ? (float)(nb.ny - me.ny) : 0.0f;
+            v[2][kk] = in_game ? (nb.nsp - me.nsp) : 0.0f;
+            v[3][kk] = in_game ? (nb.nac - me.nac) : 0.0f;
+            v[4][kk] = in_game ? (nb.ndir - me.ndir) : 0.0f;
+            v[5][kk] = (float)(nb.type_sig & 1);
+            v[6][kk] = (float)((nb.type_sig >> 1) & 1);
+          }
+          float *row = obs_blk + (long)mq * F + 4 * q;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) *(TcF4u *)(row + c * W) = TcF4u{v[c][0], v[c][1], v[c][2], v[c][3]};
+          q += sq;
+          const int carry = (q >= nq) ? 1 : 0;
+          q -= carry ? nq : 0;
+          mq += smq + carry;
+          iq += siq + carry;
+          iq -= (iq >= N) ? N : 0;
+        }
+      } else
       for (int t = tid; t < items; t += T_) {
         const int ebase = m - i;              // first agent of this row's replica
         const bool in_game = l.sig[m] != 0;
