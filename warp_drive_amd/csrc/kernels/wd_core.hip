@@ -275,6 +275,21 @@ __global__ void wd_delay(unsigned long long ticks_10ns) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_10ns) __builtin_amdgcn_s_sleep(8);
 }
 
+// Write-bandwidth probe (scripts/write_pattern_probe.py): every block streams `floats_per_block`
+// floats into its own contiguous slice of `out` (slice b starts at b * slice_stride floats), `vec`
+// floats per lane per store (1 or 4).  Shows what the HBM write path gives to the rollout's access
+// pattern -- thousands of blocks, each writing one replica's contiguous rows -- as opposed to a
+// grid-stride fill.
+__global__ void wd_write_probe(float *out, long slice_stride, int floats_per_block, int vec, float value) {
+  float *dst = out + (long)blockIdx.x * slice_stride;
+  if (vec == 4) {
+    for (int i = 4 * threadIdx.x; i + 3 < floats_per_block; i += 4 * blockDim.x)
+      *(float4 *)(dst + i) = make_float4(value, value, value, value);
+  } else {
+    for (int i = threadIdx.x; i < floats_per_block; i += blockDim.x) dst[i] = value;
+  }
+}
+
 // Evaluates the device restatements of numpy's float32 routines so the GPU parity
 // suite can compare them bit-for-bit with numpy on the host (tests/test_gpu_math.py).
 __global__ void wd_test_math(const float *__restrict__ a, const float *__restrict__ b,

@@ -314,7 +314,11 @@ class TagContinuous(CUDAEnvironmentContext):
         # 256 threads = one wavefront per SIMD: measured 1.3x faster than the denser 320-thread
         # packing (3 replicas) whose 5 wavefronts load the 4 SIMDs unevenly
         max_threads = int(os.environ.get("WD_TC_MAX_THREADS", "256"))  # override: geometry experiments
-        epb, block, grid = self.cuda_function_manager.packed_geometry(self.num_agents, max_threads=max_threads)
+        # full observations are bound by the store path: 4-wave blocks keep twice the stores in flight
+        # (scripts/write_pattern_probe.py: 2000 x 299 KB slices, 16-byte stores: 3.7 TB/s at 128 threads,
+        # 5.2 TB/s at 256); with K neighbours the two geometries measure the same
+        epb, block, grid = self.cuda_function_manager.packed_geometry(
+            self.num_agents, max_threads=max_threads, prefer_large=bool(self.use_full_observation))
         if "WD_TC_GRID" in os.environ:  # experiments: fewer blocks, each looping over replica groups
             grid = (min(grid[0], int(os.environ["WD_TC_GRID"])), 1)
         return epb, block, grid

@@ -324,7 +324,7 @@ class HIPFunctionManager(CUDAFunctionManager):
     _cuda_function_names = property(lambda self: self._function_names)
 
     # ---- wave64-aware geometry for replica-packed kernels
-    def packed_geometry(self, n_agents: Optional[int] = None, max_threads: int = 512):
+    def packed_geometry(self, n_agents: Optional[int] = None, max_threads: int = 512, prefer_large: bool = False):
         """(envs_per_block, block, grid): pack whole replicas into a block so that lanes are
         not wasted (105 agents: 3 replicas fill 315 of 320 lanes; 5 agents: 12 per wave)."""
         N = int(self._num_agents if n_agents is None else n_agents)
@@ -338,7 +338,7 @@ class HIPFunctionManager(CUDAFunctionManager):
             if threads > max_threads:
                 break
             waste = 1.0 - epb * N / threads
-            if best is None or waste < best[0] - 1e-9:
+            if best is None or waste < best[0] - 1e-9 or (prefer_large and waste < best[0] + 1e-9):
                 best = (waste, epb, threads)
         _, epb, threads = best
         epb = threads // N  # exactly what the kernels derive from blockDim.x
