@@ -114,7 +114,7 @@ __global__ void HipClassicControlCartPoleEnvTick(
       observation_arr[env] = s;
       reward_arr[env] = 1.0f;
       done_arr[env] = fin ? 1 : 0;
-      state_arr[env] = s;
+      if (fin || k == ticks - 1) state_arr[env] = s;  // otherwise the state stays in registers
       // ---- reset in place (reset.cu:9-75 for every registered array); `_done_` stays set
       if (fin) {
         for (int r = 0; r < n_reset_arrays; ++r) {
