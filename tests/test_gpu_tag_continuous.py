@@ -342,3 +342,28 @@ def test_many_agents_paths(n_runners, K, full_obs):
                use_full_observation=full_obs, num_other_agents_observed=K, tagging_distance=0.2,
                runner_exits_game_after_tagged=True)
     _run_lockstep(cfg, E=3, ticks=8, seed=n_runners)
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_random_configurations(case):
+    """seeded random shapes and reward settings: agent counts around the wavefront / block boundaries,
+    K from 1 to N-1, both observation modes, both exit rules, replica counts that do not fill a block"""
+    rng = np.random.RandomState(1000 + case)
+    n_taggers = int(rng.randint(1, 7))
+    n_runners = int(rng.choice([1, 2, 5, 30, 58, 59, 60, 63, 64, 65, 100, 123, 124, 127, 130]))
+    N = n_taggers + n_runners
+    full = bool(rng.randint(0, 2)) and N <= 70
+    K = int(rng.randint(1, min(N - 1, 33) + 1)) if N > 2 else 1
+    cfg = dict(num_taggers=n_taggers, num_runners=n_runners, grid_length=float(rng.choice([2.0, 7.5, 20.0])),
+               episode_length=int(rng.randint(3, 12)), seed=int(rng.randint(1, 10 ** 6)),
+               max_speed=float(rng.choice([0.5, 1.0, 2.5])), max_acceleration=0.25, min_acceleration=-0.25,
+               max_turn=float(rng.choice([0.8, 2.356])), min_turn=-float(rng.choice([0.8, 2.356])),
+               num_acceleration_levels=int(rng.randint(1, 9)), num_turn_levels=int(rng.randint(1, 9)),
+               skill_level_runner=float(rng.choice([0.7, 1.0])), skill_level_tagger=float(rng.choice([0.9, 1.0, 1.3])),
+               use_full_observation=full, num_other_agents_observed=K,
+               tagging_distance=float(rng.choice([0.02, 0.3, 1.0])), tag_reward_for_tagger=float(rng.choice([1.0, 10.0])),
+               tag_penalty_for_runner=-float(rng.choice([1.0, 10.0])), step_penalty_for_tagger=-float(rng.choice([0.0, 0.01])),
+               step_reward_for_runner=float(rng.choice([0.0, 0.01])), edge_hit_penalty=-float(rng.choice([0.0, 0.5])),
+               end_of_game_reward_for_runner=float(rng.choice([0.0, 1.0])),
+               runner_exits_game_after_tagged=bool(rng.randint(0, 2)))
+    _run_lockstep(cfg, E=int(rng.choice([1, 2, 3, 7, 33])), ticks=14, seed=case)
