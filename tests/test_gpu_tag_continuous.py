@@ -198,8 +198,15 @@ def test_bench_full_size_properties():
     np.testing.assert_array_equal(pull(w, OBS)[: 8 * G: G], orc.obs.astype(np.float32))
 
 
-@pytest.mark.parametrize("full_obs", [False, True])
-def test_fused_tick_kernel(full_obs):
+@pytest.mark.parametrize("full_obs,acc_levels,turn_levels,runners,K,E", [
+    (False, 6, 8, 30, 6, 23), (True, 6, 8, 30, 6, 23),
+    (False, 30, 40, 17, 5, 9),     # probability rows longer than the register path (31 / 41 actions)
+    (False, 1, 1, 100, 10, 5),     # two actions per head, the benchmark's agent count
+    (False, 3, 3, 130, 4, 3),      # more than 128 agents: LDS candidate lists
+    (True, 2, 5, 60, 3, 4),        # full observations whose width is a multiple of four (16-byte stores)
+    (False, 70, 3, 10, 3, 2),      # action table larger than its LDS copy (71 > 64 entries)
+])
+def test_fused_tick_kernel(full_obs, acc_levels, turn_levels, runners, K, E):
     """HipTagContinuousTick: sampling + step + in-kernel reset in ONE launch.  The actions it
     sampled are pulled back and replayed through the oracle; finished replicas must already
     be reset when the launch returns while `_done_` still reports them for the trainer."""
@@ -212,11 +219,13 @@ def test_fused_tick_kernel(full_obs):
     from warp_drive_amd.env_wrapper import EnvWrapper
 
     require_gpu()
-    cfg = dict(num_taggers=4, num_runners=30, grid_length=6.0, episode_length=11, seed=5, max_speed=0.6,
-               max_acceleration=0.3, min_acceleration=-0.3, num_acceleration_levels=6, num_turn_levels=8,
-               use_full_observation=full_obs, num_other_agents_observed=6, tagging_distance=0.12,
-               edge_hit_penalty=-0.2, step_reward_for_runner=0.01, runner_exits_game_after_tagged=True)
-    E = 23
+    n_taggers = 5 if (full_obs and runners == 60) else 4   # 65 agents -> 64 neighbour slots
+    cfg = dict(num_taggers=n_taggers, num_runners=runners, grid_length=6.0, episode_length=11, seed=5, max_speed=0.6,
+               max_acceleration=0.3, min_acceleration=-0.3, num_acceleration_levels=acc_levels,
+               num_turn_levels=turn_levels, use_full_observation=full_obs, num_other_agents_observed=K,
+               tagging_distance=0.12, edge_hit_penalty=-0.2, step_reward_for_runner=0.01,
+               runner_exits_game_after_tagged=True)
+    na, nt = acc_levels + 1, turn_levels + 1
     w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
     w.reset_all_envs()
     sampler = HIPSampler(w.cuda_function_manager)
@@ -225,12 +234,12 @@ def test_fused_tick_kernel(full_obs):
                                       push_data_batch_placeholders=False)
     rng = np.random.RandomState(0)
     N = w.n_agents
-    probs = [torch.from_numpy(rng.dirichlet(np.ones(a), size=(E, N)).astype(np.float32)).cuda() for a in (7, 9)]
+    probs = [torch.from_numpy(rng.dirichlet(np.ones(a), size=(E, N)).astype(np.float32)).cuda() for a in (na, nt)]
     engine = RolloutEngine(w, sampler, probabilities=probs)
     assert engine.fused and engine.step_kernel_name.startswith("HipTagContinuousTick")
     orc = TagContinuousOracle(num_envs=E, **cfg)
     stats = {"near_tie_rows": 0, "rows": 0}
-    counts = [np.zeros(7), np.zeros(9)]
+    counts = [np.zeros(na), np.zeros(nt)]
     finished_total = 0
     from oracle.core_np import fused_tick_uniforms, sample_actions_counting
     from warp_drive_amd.managers import hip_driver as drv
@@ -249,9 +258,9 @@ def test_fused_tick_kernel(full_obs):
         u0, u1 = fused_tick_uniforms(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
         np.testing.assert_array_equal(a[..., 0], sample_actions_counting(probs_host[0], u0.reshape(E, N)))
         np.testing.assert_array_equal(a[..., 1], sample_actions_counting(probs_host[1], u1.reshape(E, N)))
-        assert a[..., 0].max() < 7 and a[..., 1].max() < 9 and a.min() >= 0
-        counts[0] += np.bincount(a[..., 0].reshape(-1), minlength=7)
-        counts[1] += np.bincount(a[..., 1].reshape(-1), minlength=9)
+        assert a[..., 0].max() < na and a[..., 1].max() < nt and a.min() >= 0
+        counts[0] += np.bincount(a[..., 0].reshape(-1), minlength=na)
+        counts[1] += np.bincount(a[..., 1].reshape(-1), minlength=nt)
         orc.step(a)
         np.testing.assert_array_equal(pull(w, REW), orc.rewards, err_msg=f"rewards t={t}")
         np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")  # still set
