@@ -376,3 +376,25 @@ def test_random_configurations(case):
                end_of_game_reward_for_runner=float(rng.choice([0.0, 1.0])),
                runner_exits_game_after_tagged=bool(rng.randint(0, 2)))
     _run_lockstep(cfg, E=int(rng.choice([1, 2, 3, 7, 33])), ticks=14, seed=case)
+
+
+def test_rollout_falls_back_when_the_tick_does_not_fit_lds():
+    """~1000 agents x two 21-way heads: the probability slabs exceed a workgroup's LDS, so the rollout
+    engine must use the separate launches (and still run)"""
+    import torch
+    from tests.hip_harness import pull
+    from warp_drive_amd.managers.function_manager import HIPSampler
+    from warp_drive_amd.rollout import RolloutEngine
+
+    cfg = dict(num_taggers=4, num_runners=1000, grid_length=40.0, episode_length=5, seed=3,
+               num_acceleration_levels=20, num_turn_levels=20, use_full_observation=False,
+               num_other_agents_observed=3, tagging_distance=0.05)
+    w = _mk(cfg, 2)
+    assert not w.env.can_fuse_tick()
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=1)
+    engine = RolloutEngine(w, sampler)
+    assert not engine.fused and len(engine.entry_names) == 4
+    engine.run(7)
+    torch.cuda.synchronize()
+    assert pull(w, "_timestep_").max() <= 5 and np.isfinite(pull(w, "loc_x")).all()

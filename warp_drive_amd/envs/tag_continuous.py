@@ -340,6 +340,15 @@ class TagContinuous(CUDAEnvironmentContext):
         args, epb, block, grid = self._range_args(env_range)
         return self.cuda_step, args, block, grid, self.lds_bytes(epb)
 
+    LDS_PER_WORKGROUP = 160 * 1024  # gfx950
+
+    def can_fuse_tick(self):
+        """False when the fused tick's LDS image (work area or the two probability slabs, whichever is
+        larger) does not fit a workgroup -- e.g. ~1000 agents with 21-way action heads; the rollout then
+        uses the separate sampler / step / reset launches."""
+        epb, _, _ = self._geometry()
+        return self.lds_bytes(epb, fused=True) <= self.LDS_PER_WORKGROUP
+
     def tick_launch(self, sampler, probabilities, resetter, env_range=None):
         """Fused rollout tick: sample both action heads + step + reset finished replicas in ONE
         launch (HipTagContinuousTick[_K<k>]).  probabilities = [acceleration, turn] float32 CUDA

@@ -61,7 +61,8 @@ class RolloutEngine:
         # (restarts from a reset pool draw random members: that stays with the pool reset kernel)
         self.fused = bool(fused and reset_done and hasattr(env_wrapper.env, "tick_launch")
                           and H == getattr(env_wrapper.env, "TICK_HEADS", 2)
-                          and len(dm.reset_target_to_pool) == 0)
+                          and len(dm.reset_target_to_pool) == 0
+                          and getattr(env_wrapper.env, "can_fuse_tick", lambda: True)())
         self.group_plans, self.group_streams = [], []
         # env ticks per launch (> 1 only for envs whose fused kernel loops over ticks, fixed policy)
         self.ticks_per_launch = int(getattr(env_wrapper.env, "ticks_per_launch", 1)) if self.fused else 1
