@@ -22,8 +22,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# kernel arguments in device memory instead of host-coherent memory (measured on MI355X: one
+# TagContinuous tick 54.3 -> 50.5 us, TagGridWorld 10.9 -> 7.9 us); must be set before HIP initialises
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
