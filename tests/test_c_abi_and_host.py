@@ -37,13 +37,27 @@ def test_header_symbols_are_exported(built):
     assert "amdhip64" not in needed
 
 
+def test_header_is_plain_c_and_binds_from_c(built, tmp_path):
+    """include/wd_hip.h must compile as C (cgo / JNI / N-API bindings) and the entry points must
+    resolve and follow the error convention from a program that knows nothing about Python or torch"""
+    exe = str(tmp_path / "c_abi_consumer")
+    src = os.path.join(ROOT, "tests", "c", "c_abi_consumer.c")
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                    "-ldl"], check=True)
+    out = subprocess.run([exe, built.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("version ")
+
+
 def test_code_object_has_all_kernels(built):
     from warp_drive_amd.managers.function_manager import DEFAULT_FUNCTION_NAMES
 
     blob = open(built.HSACO_PATH, "rb").read()
     wanted = list(DEFAULT_FUNCTION_NAMES) + ["HipTagGridWorldStep", "HipTagContinuousStep",
                                              "HipTagContinuousStep_K10", "HipClassicControlCartPoleEnvStep",
-                                             "testkernel", "kIndexToActionArr", "wd_test_math"]
+                                             "testkernel", "kIndexToActionArr", "wd_test_math", "HipTagContinuousTick_K10",
+                                             "HipTagContinuousTick", "HipTagGridWorldTick",
+                                             "HipClassicControlCartPoleEnvTick"]
     for name in wanted:
         assert name.encode() in blob, f"{name} is not in the code object"
     assert b"gfx950" in blob
