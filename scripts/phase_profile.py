@@ -67,6 +67,16 @@ for fused in (True, False):
     print("mean lifetime by blockIdx % 8 (XCD):", " ".join(f"{life[i::8].mean():.2f}" for i in range(8)))
     print("mean lifetime by blockIdx quartile:", " ".join(f"{life[q * len(life) // 4:(q + 1) * len(life) // 4].mean():.2f}" for q in range(4)))
     print("mean start by blockIdx quartile:", " ".join(f"{start[q * len(life) // 4:(q + 1) * len(life) // 4].mean():.2f}" for q in range(4)))
+    # which phases stretch in the blocks that finish last?  (oldest-first issue arbitration lets the
+    # first-launched blocks run ahead; the kernel ends with the slowest)
+    ok = (st[:, 4] > st[:, 3]) & (st[:, 7] > st[:, 6])  # wave 0 ran the search (agent 0 in the game)
+    order_by_end = np.argsort(st[:, 12])
+    fast, slow = order_by_end[: len(order_by_end) // 10], order_by_end[-(len(order_by_end) // 10):]
+    for label, idx in (("fastest 10 % of blocks", fast), ("slowest 10 % of blocks", slow)):
+        idx = idx[ok[idx]]
+        seg = " ".join(f"{names[b][:14]}={np.mean(st[idx, b] - st[idx, a_]) / 1000:5.1f}k"
+                       for a_, b in zip(order[:-1], order[1:]))
+        print(f"{label}: {seg}  | lifetime {np.mean(st[idx, 12] - st[idx, 11]) / 100:.1f} us")
     tot = st[:, 10] - st[:, 0]
     print(f"{'total':<22} mean={tot.mean():10.0f}   spread of block start = {st[:,0].max()-st[:,0].min()}")
 
