@@ -3,22 +3,32 @@
 
 Workload (BASELINE.json configs[2]): TagContinuous, 5 taggers x 100 runners, partial
 observation K = 10, run_configs/tag_continuous.yaml physics, num_envs = 2000 PER GPU.
-One "step" = one rollout tick over all replicas of a rank:
-    sample_actions (2 heads, uniform synthetic policy output resident in HBM)
-    -> HipTagContinuousStep_K10 -> reset_when_done_fused
+One "step" = one rollout tick over all replicas of a rank = ONE launch of the fused tick kernel
+HipTagContinuousTick_K10: sample both action heads (uniform synthetic policy output resident
+in HBM) -> step -> reset finished replicas in place (`--unfused`: the same tick as four
+launches: sample_actions x2, HipTagContinuousStep_K10, reset_when_done_fused),
 replayed from C through the C-ABI (include/wd_hip.h) on the stream torch uses.
 value = total env-steps of all ranks / max-over-ranks wall time of the timed region.
 Replicas shard trivially (weak scaling): no collective in the data path; for N > 1 the
 only RCCL traffic is the barrier + the max-reduction of the timing.
 
+The timed region holds the K launches and nothing else (no event records).  The dominant
+kernel's average launch duration (roofline.achieved) is measured with HIP events on the launch
+stream around groups of 8 back-to-back launches, in two passes of 512 launches just before and
+just after the timed region.
+
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        (N > 1 without a launcher: bench.py starts its own N ranks through torch.distributed.run)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -133,11 +143,25 @@ def main():
 
     from warp_drive_amd import distributed as wdd
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU,
+        # localhost rendezvous), which print the JSON line themselves
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank, local_rank, world = wdd.rank_info()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the HIP path"
-    torch.cuda.set_device(local_rank)
-    wdd.init_process_group(backend="nccl", device_id=local_rank)  # RCCL; no-op for one rank
+    device = wdd.device_index(local_rank)
+    torch.cuda.set_device(device)
+    wdd.init_process_group(backend="nccl", device_id=device)  # RCCL; no-op for one rank
 
     from warp_drive_amd.env_wrapper import EnvWrapper
     from warp_drive_amd.envs.tag_continuous import TagContinuous
@@ -163,10 +187,12 @@ def main():
         E = args.num_envs or 100000
         env_obj = CUDAClassicControlCartPoleEnv(**cfg)
         env_obj.ticks_per_launch = max(1, args.ticks_per_launch)
-    w = EnvWrapper(env_obj=env_obj, num_envs=E, env_backend="hip", process_id=local_rank)
+    w = EnvWrapper(env_obj=env_obj, num_envs=E, env_backend="hip", process_id=device)
     w.reset_all_envs()
     sampler = HIPSampler(w.cuda_function_manager)
-    sampler.init_random(seed=cfg["seed"] + rank)  # seed + device id, trainer_base.py:249-252
+    seed = wdd.rank_seed(cfg["seed"], rank)  # seed + rank, trainer_base.py:249-252
+    sampler.init_random(seed=seed)
+    seeds = wdd.gather_ints(seed)
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
     engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused,
@@ -187,25 +213,26 @@ def main():
         torch.cuda.set_stream(side)
     run(warmup)
     barrier()
-    # sample the dominant kernel's duration with HIP events on the launch stream inside the
-    # timed region (<= 64 evenly spaced ticks, so the events do not perturb the measurement)
-    if args.mode == "plan":
-        engine.plan.enable_timing(engine.step_entry, sample_stride=max(1, steps // 64), max_samples=64)
+
+    def time_kernel(launches=512):
+        """average launch duration of the dominant kernel: HIP events on the launch stream around
+        groups of 8 back-to-back launches (outside the timed region)"""
+        engine.plan.enable_timing(engine.step_entry, 8, max(1, launches // 8))
+        engine.run(launches)
+        torch.cuda.synchronize()
+        ms, n = engine.plan.read_timing()
+        engine.plan.enable_timing(-1, 1, 1)
+        return ms, n
+
+    kern_ms, kern_n = time_kernel()   # also leaves the clocks where a long run has them
     barrier()
     t0 = time.perf_counter()
-    run(steps)
+    run(steps)                        # the timed region: K launches, no event records
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = wdd.max_over_ranks(elapsed)
-
-    kern_ms, kern_n = (engine.plan.read_timing() if args.mode == "plan" else (0.0, 0))
-    if args.mode == "graph" or kern_n == 0:
-        # graph replay cannot carry event records: time the same launch back to back instead
-        engine.plan.enable_timing(engine.step_entry, 1, 64)
-        engine.run(64)
-        torch.cuda.synchronize()
-        kern_ms, kern_n = engine.plan.read_timing()
-    engine.plan.enable_timing(-1, 1, 1)
+    ms2, n2 = time_kernel()
+    kern_ms, kern_n = kern_ms + ms2, kern_n + n2
 
     if rank == 0:
         N = w.n_agents
@@ -227,13 +254,18 @@ def main():
         bytes_per_launch = bytes_per_env_step * E * engine.ticks_per_launch
         kern_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they
+        # were collected on exactly the code object loaded now and at this shape, else null
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
+                from warp_drive_amd.managers import hip_driver
+
+                sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
                 rec = json.load(open(pmc)).get(engine.step_kernel_name, {})
                 if (args.workload == "tag_continuous" and rec.get("num_envs") == E
-                        and rec.get("full_obs") == bool(args.full_obs)):
+                        and rec.get("full_obs") == bool(args.full_obs) and rec.get("hsaco_sha256") == sha):
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -257,13 +289,15 @@ def main():
                             f"{' (one fused launch)' if engine.fused else ''}",
                 "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode, "replica_groups": args.groups,
                 "kernels_per_tick": len(engine.entry_names), "ticks_per_launch": engine.ticks_per_launch,
-                "parallelism": f"env-replica sharding x{world}",
+                "parallelism": f"env-replica sharding x{world}", "sampler_seeds": seeds,
             },
             "roofline": {
                 "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_us": kern_s * 1e6,
                 "samples": kern_n,
+                "timing": "HIP events around groups of 8 back-to-back launches, 512 launches before + 512 "
+                          "after the timed region",
             },
         }
         if not args.no_cpu_baseline and args.workload == "tag_continuous" and world == 1:  # N = 1 only

@@ -83,3 +83,52 @@ def test_shard_replicas_covers_everything():
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
     assert shard_replicas(16000, 8, 3) == (6000, 2000)
+
+
+def _lock_worker(rank, out_dir):
+    from warp_drive_amd import build as wd_build
+
+    path = wd_build.build_kernels_locked()
+    open(os.path.join(out_dir, f"ok_{rank}"), "w").write(path)
+
+
+def test_concurrent_ranks_build_once(tmp_path):
+    """ranks started by torch.distributed.run share no Event: every rank calls the locked build
+    (what HIPFunctionManager.compile_and_load_hip does without an event messenger)"""
+    from warp_drive_amd import build as wd_build
+
+    mp.spawn(_lock_worker, args=(str(tmp_path),), nprocs=3, join=True)
+    for r in range(3):
+        assert open(tmp_path / f"ok_{r}").read() == wd_build.HSACO
+    assert os.path.exists(wd_build.HSACO)
+
+
+def test_device_index_and_backend_override(monkeypatch):
+    from warp_drive_amd import distributed as wdd
+
+    monkeypatch.delenv("WD_FORCE_DEVICE", raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert wdd.device_index() == 3 and wdd.device_index(5) == 5
+    monkeypatch.setenv("WD_FORCE_DEVICE", "0")  # N > 1 tests on a 1-GPU box
+    assert wdd.device_index() == 0 and wdd.device_index(5) == 0
+    assert wdd.gather_ints(7) == [7]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (the driver's N = 1
+    shape of the command); without a GPU the ranks stop at the loud no-GPU assertion, not before"""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("covered by tests/test_gpu_multirank.py on a GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert "bench.py needs an MI355X" in out.stderr and "but WORLD_SIZE" not in out.stderr

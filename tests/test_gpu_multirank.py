@@ -1,0 +1,71 @@
+"""The N > 1 launch path on a 1-GPU box: two ranks, both pinned to device 0 (WD_FORCE_DEVICE) and
+rendezvousing over gloo (RCCL refuses two ranks on one GPU).  Exercises what round 1 never started:
+a rank > 0 constructing EnvWrapper without an event messenger (reference protocol:
+warp_drive/training/utils/device_child_process/child_process_base.py:36-85,
+pycuda_function_manager.py:170-181), bench.py launching its own ranks, and the 2-rank DDP trainer."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ)
+    env.update(WD_FORCE_DEVICE="0", WD_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _bench(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
+                          "--num-envs", "500", "--no-cpu-baseline"] + extra,
+                         capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_started_plainly():
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    one = _bench([])
+    two = _bench(["--gpus", "2"])  # plain `python bench.py --gpus 2`: bench.py starts its own ranks
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["num_envs_per_gpu"] == 500
+    assert two["config"]["sampler_seeds"] == [274880, 274881]  # seed + rank
+    # whole-job value = all ranks' env-steps / slowest rank's time
+    assert abs(two["value"] - 2 * 500 * 20 / (two["ms_per_step"] * 20 * 1e-3)) / two["value"] < 1e-6
+    # both ranks share ONE device here, so the aggregate cannot double; it must still be the same order
+    assert 0.3 * one["value"] < two["value"] < 2.5 * one["value"]
+    assert two["roofline"]["samples"] > 0 and two["roofline"]["achieved"] > 0
+
+
+def test_train_two_ranks(tmp_path):
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    from warp_drive_amd.training.scripts import launch
+
+    cmd = launch.build_command("tag_gridworld", 2, launch.free_port(),
+                               ["--iters", "2", "--num_envs", "40", "--train_batch_size", "400",
+                                "--results_dir", str(tmp_path)])
+    out = subprocess.run(cmd, capture_output=True, text=True, env=launch.child_environment(_env()), cwd=ROOT,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    recs = []
+    for rank in range(2):  # per-device result files, trainer_base.py:627-630
+        path = tmp_path / f"results_device_{rank}.json"
+        assert path.exists(), os.listdir(tmp_path)
+        recs.append([json.loads(l) for l in open(path)])
+    assert recs[0][-1]["Iterations Completed"] == 2 and recs[1][-1]["Iterations Completed"] == 2
+    # DDP keeps the replicas' models identical: rank 0 saves, and the ranks' losses differ (own replicas)
+    assert any(f.endswith(".state_dict") for f in os.listdir(tmp_path))

@@ -26,6 +26,9 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 KERNEL_FLAGS = [
     "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # the fused tick kernels restore registered arrays through the reset table's untyped 32-bit
+    # pointers, which alias the typed kernel arguments: no type-based alias analysis
+    "-fno-strict-aliasing",
 ]
 
 
@@ -62,6 +65,22 @@ def build_kernels(force=False, verbose=False, extra_flags=()):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     return HSACO
+
+
+def build_kernels_locked(force=False, verbose=False):
+    """build_kernels() under an exclusive file lock: safe to call from every rank of a node at once
+    (ranks started by torch.distributed.run share no Event); the first caller builds, the others
+    block on the lock and then find the code object fresh."""
+    import fcntl
+
+    if not force and os.path.exists(HSACO) and not os.access(CSRC, os.W_OK):
+        return HSACO  # read-only install: use what is there
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build_kernels(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def build_all(force=False, verbose=False):

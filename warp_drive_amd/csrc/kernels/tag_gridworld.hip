@@ -68,11 +68,11 @@ __device__ __forceinline__ void gw_write_row(float *row, const float *fx, const 
 // divisions, tag_gridworld_step_pycuda.cu:29-51) is left in the copy loop.
 template <bool FUSED>
 __device__ __forceinline__ void gw_step_impl(
-    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
-    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    int *states_x_arr, int *states_y_arr, int *actions_arr,
+    int *done_arr, float *rewards_arr, float *obs_arr,
     float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
     float step_cost_for_tagger, int use_full_observation, int world_boundary,
-    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs, const GwFuse &fz,
+    int *env_timestep_arr, int episode_length, int n_agents, int n_envs, const GwFuse &fz,
     int *s_mem) {
   const int N = n_agents;
   const int epb = max(1, (int)blockDim.x / N);  // replicas per block
@@ -199,11 +199,11 @@ __device__ __forceinline__ void gw_step_impl(
 extern "C" {
 
 __global__ void HipTagGridWorldStep(
-    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
-    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    int *states_x_arr, int *states_y_arr, int *actions_arr,
+    int *done_arr, float *rewards_arr, float *obs_arr,
     float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
     float step_cost_for_tagger, int use_full_observation, int world_boundary,
-    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs) {
+    int *env_timestep_arr, int episode_length, int n_agents, int n_envs) {
   extern __shared__ __attribute__((aligned(16))) int gw_smem[];
   gw_step_impl<false>(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
                       tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger, use_full_observation,
@@ -213,11 +213,11 @@ __global__ void HipTagGridWorldStep(
 // Fused rollout tick: sample the action + step + reset finished replicas in ONE launch (the reference
 // needs the sampler launch, the step, and one reset launch per registered array, trainer_base.py:392-426).
 __global__ void HipTagGridWorldTick(
-    int *__restrict__ states_x_arr, int *__restrict__ states_y_arr, int *__restrict__ actions_arr,
-    int *__restrict__ done_arr, float *__restrict__ rewards_arr, float *__restrict__ obs_arr,
+    int *states_x_arr, int *states_y_arr, int *actions_arr,
+    int *done_arr, float *rewards_arr, float *obs_arr,
     float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
     float step_cost_for_tagger, int use_full_observation, int world_boundary,
-    int *__restrict__ env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
+    int *env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
     const float *probs, int n_actions, const void *reset_table, int n_reset_arrays, int stream_tag) {
   extern __shared__ __attribute__((aligned(16))) int gw_smem[];
   GwFuse fz;

@@ -16,12 +16,23 @@ def rank_info():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def device_index(local_rank=None):
+    """HIP device a rank drives: its local rank (one process per GPU).  WD_FORCE_DEVICE pins every
+    rank to one device instead -- used by the tests that run the N > 1 path on a 1-GPU box."""
+    forced = os.environ.get("WD_FORCE_DEVICE")
+    if forced not in (None, ""):
+        return int(forced)
+    return int(rank_info()[1] if local_rank is None else local_rank)
+
+
 def init_process_group(backend=None, device_id=None):
     rank, local_rank, world = rank_info()
     if world == 1:
         return rank, local_rank, world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # RCCL refuses two ranks on one GPU; the 1-GPU tests of the N > 1 path ask for gloo here
+    backend = os.environ.get("WD_DIST_BACKEND") or backend
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kwargs = {}
@@ -68,6 +79,15 @@ def sum_over_ranks(value):
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_ints(value):
+    """[value of rank 0, value of rank 1, ...] on every rank"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(value)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, int(value))
+    return [int(v) for v in out]
 
 
 def aggregate_throughput(units_this_rank, seconds_this_rank):

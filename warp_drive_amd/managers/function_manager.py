@@ -276,18 +276,26 @@ class HIPFunctionManager(CUDAFunctionManager):
                              template_runner_file=None, template_path=None,
                              default_functions_included: bool = True, customized_env_registrar=None,
                              event_messenger=None):
-        """Rank 0 (re)builds the in-tree code object if stale, the others wait for its Event."""
-        if self._process_id > 0:
-            assert event_messenger is not None, "Event messenger is required to sync up the compilation status among processes."
-            event_messenger.wait(timeout=120)
-            if not event_messenger.is_set():
-                raise Exception(f"Process {self._process_id} fails to get the successful compilation message ... ")
-        else:
-            from warp_drive_amd import build as wd_build
+        """(Re)build the in-tree code object if it is stale, exactly once per node, then load it.
 
-            wd_build.build_kernels()
-            if event_messenger is not None:
+        With an `event_messenger` (the reference's own child-process launcher) the protocol is the
+        reference's: process 0 builds and sets the Event, the others wait for it
+        (pycuda_function_manager.py:170-181,:227-228).  Without one -- ranks started by
+        `torch.distributed.run`, which shares no multiprocessing.Event -- every rank takes an
+        exclusive file lock around the staleness check, so the first one in builds and the rest find
+        a fresh code object; who builds is independent of the device a rank drives."""
+        from warp_drive_amd import build as wd_build
+
+        if event_messenger is not None:
+            if self._process_id > 0:
+                event_messenger.wait(timeout=120)
+                if not event_messenger.is_set():
+                    raise Exception(f"Process {self._process_id} fails to get the successful compilation message ... ")
+            else:
+                wd_build.build_kernels()
                 event_messenger.set()
+        else:
+            wd_build.build_kernels_locked()
         self.load_hip_from_binary_file(default_functions_included=default_functions_included)
 
     compile_and_load_cuda = compile_and_load_hip
@@ -354,6 +362,7 @@ class HIPSampler(CUDASampler):
     (numba_function_manager.py:248-364)."""
 
     ROWS_PER_BLOCK = 256
+    MAX_DYNAMIC_LDS = 64 * 1024  # dynamic LDS a plain launch may ask for
 
     def __init__(self, function_manager: HIPFunctionManager):
         super().__init__(function_manager)
@@ -384,8 +393,11 @@ class HIPSampler(CUDASampler):
         rollout launch plan."""
         stride = int(n_actions) | 1  # odd row stride: conflict-free LDS reads
         rows = self.ROWS_PER_BLOCK
-        while rows > _WAVE and rows * stride * 4 > 64 * 1024:
+        while rows > 8 and rows * stride * 4 > self.MAX_DYNAMIC_LDS:  # long rows: fewer rows per block
             rows //= 2
+        assert rows * stride * 4 <= self.MAX_DYNAMIC_LDS, (
+            f"sample_actions stages {rows} rows of {n_actions} probabilities in LDS: more than "
+            f"{self.MAX_DYNAMIC_LDS // (8 * 4) - 1} actions per head are not supported")
         grid = max(1, min(8192, (int(n_rows) + rows - 1) // rows))
         args = (self._rng_state, distribution_ptr, action_ptr, drv.DevicePtr(0), np.int32(n_rows),
                 np.int32(n_actions), np.int32(use_argmax), np.int32(stride), tag, np.int32(out_stride),
@@ -449,6 +461,7 @@ class HIPEnvironmentReset(CUDAEnvironmentReset):
         self.undo = fm.get_function("undo_done_flag_and_reset_timestep")
         self._table = None
         self._table_names = None
+        self._retired_tables = []
         self._pool_rng = None
 
     # ---- custom reset kernels (same contract as the reference)
@@ -485,7 +498,9 @@ class HIPEnvironmentReset(CUDAEnvironmentReset):
             entries[i] = (int(data_manager.device_data(name)), int(data_manager.device_data(f"{name}_at_reset")),
                           int(np.prod(shape[1:])) if len(shape) > 1 else 1, 0)
         if self._table is not None:
-            self._table.free()
+            # launch plans / hipGraphs built earlier hold the old table's address: it stays allocated
+            # (and valid for the arrays it lists) until this object goes away
+            self._retired_tables.append(self._table)
         self._table = drv.mem_alloc(max(entries.nbytes, 8))
         if entries.nbytes:
             drv.memcpy_htod(self._table, entries.view(np.uint8))
@@ -562,7 +577,8 @@ class HIPEnvironmentReset(CUDAEnvironmentReset):
                   data_manager.meta_info("n_envs"), block=(256, 1, 1), grid=(max(1, min(4096, (n + 255) // 256)), 1))
 
     def __del__(self):
-        for p in (getattr(self, "_table", None), getattr(self, "_pool_rng", None)):
+        for p in [getattr(self, "_table", None), getattr(self, "_pool_rng", None)] + list(
+                getattr(self, "_retired_tables", [])):
             if p is not None:
                 try:
                     p.free()

@@ -38,16 +38,16 @@ def setup_trainer(env_name, overrides=None, results_dir=None, verbose=True):
     for section, kv in (overrides or {}).items():
         config.setdefault(section, {}).update(kv)
     rank, local_rank, world = wdd.rank_info()
-    torch.cuda.set_device(local_rank)
-    wdd.init_process_group(backend="nccl", device_id=local_rank)
+    device = wdd.device_index(local_rank)  # one rank per GPU: device = local rank
+    torch.cuda.set_device(device)
+    wdd.init_process_group(backend="nccl", device_id=device)
     env_cfg = dict(config["env"])
-    if "seed" in env_cfg and env_name != "single_cartpole":
-        env_cfg["seed"] = env_cfg["seed"]  # identical start state on every rank; actions differ by seed + rank
+    # (identical seeded start state on every rank; the action streams differ by seed + rank)
     env = _ENVS[env_name](**env_cfg)
     wrapper = EnvWrapper(env_obj=env, num_envs=int(config["trainer"]["num_envs"]), env_backend="hip",
-                         process_id=local_rank)
+                         process_id=device)
     return Trainer(env_wrapper=wrapper, config=config, policy_tag_to_agent_id_map=policy_map_for(env_name, env),
-                   device_id=local_rank, results_dir=results_dir, verbose=verbose)
+                   device_id=device, results_dir=results_dir, verbose=verbose)
 
 
 def main():

@@ -93,7 +93,11 @@ class Trainer:
         self.num_envs = E
         self.batch_len = max(1, int(tcfg["train_batch_size"]) // E)  # ticks per training iteration
         self.train_batch_size = self.batch_len * E
-        self.num_iters = int(tcfg["num_episodes"]) * env_wrapper.episode_length // self.batch_len
+        # total env steps (all replicas) // steps per iteration, trainer_base.py:268-275
+        self.num_iters = int(tcfg["num_episodes"]) * env_wrapper.episode_length // self.train_batch_size
+        if self.num_iters == 0:
+            raise ValueError("Not enough steps to even perform a single training iteration!. Please increase the "
+                             "number of episodes or reduce the training batch size.")
         self.save_dir = results_dir or os.path.join(config["saving"]["basedir"], config["saving"]["name"],
                                                     config["saving"]["tag"], str(int(time.time())))
         if self.rank == 0:
@@ -197,9 +201,9 @@ class Trainer:
                     self.probs[h].index_copy_(1, ids, p)
         self.engine.run(1)  # sample + step (+ reset when fused), asynchronous on torch's stream
         self.done_batch.index_copy_(0, b, self.done.unsqueeze(0))
+        finished = (self.done > 0).to(torch.float32)  # before the reset launch clears `_done_`
         if not self.engine.fused:
             self.w.reset_only_done_envs()
-        finished = (self.done > 0).to(torch.float32)
         for pol in self.policies:
             ids = self.ids[pol]
             a = self.actions if len(self.policies) == 1 else self.actions.index_select(1, ids)
