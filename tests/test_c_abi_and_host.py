@@ -149,8 +149,12 @@ def test_packed_geometry_fills_wavefronts(built):
     fm = CUDAFunctionManager(num_agents=105, num_envs=2000)
     assert fm.block == (105, 1, 1) and fm.grid == (2000, 1)  # the reference's default geometry
     geo = HIPFunctionManager.packed_geometry
-    epb, block, grid = geo(fm, 105, 512)
-    assert (epb, block, grid) == (3, (320, 1, 1), (667, 1))
+    # the product geometry (envs/tag_continuous.py::_geometry: blocks of at most 256 threads):
+    # 105 agents -> one replica per 128-thread block, one block per replica
+    epb, block, grid = geo(fm, 105, 256)
+    assert (epb, block, grid) == (1, (128, 1, 1), (2000, 1))
+    # a 512-thread budget would pack 3 replicas into 5 wavefronts (315 of 320 lanes)
+    assert geo(fm, 105, 512) == (3, (320, 1, 1), (667, 1))
     epb, block, grid = geo(fm, 5, 256)
     assert block[0] % 64 == 0 and epb == block[0] // 5 and epb * 5 / block[0] > 0.99
     assert grid[0] * epb >= 2000

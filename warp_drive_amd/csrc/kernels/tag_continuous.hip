@@ -1,4 +1,4 @@
-// tag_continuous.hip -- TagContinuous step for gfx950.
+// tag_continuous.hip -- TagContinuous step / fused rollout tick for gfx950.
 //
 // Semantics: the reference CPU step, example_envs/tag_continuous/tag_continuous.py
 //   update_state :339-401, compute_distance :403-420, k_nearest_neighbors :422-444,
@@ -7,88 +7,45 @@
 // disagrees with its CPU step the CPU wins: stable (distance, id) neighbour order,
 // tag counts accumulated without races, no end-of-game bonus for a runner tagged out
 // on the last tick.  Argument order is the reference kernel's (:351-385) plus trailing
-// n_envs and the two action-table lengths; the two O(N^2) global scratch arrays it sorts in HBM
-// (neighbor_distances, neighbor_ids_sorted_by_distance; :167-199) are accepted and
-// never touched.
+// n_envs, the two action-table lengths and the first replica of the launch; the two O(N^2)
+// global scratch arrays it sorts in HBM (neighbor_distances,
+// neighbor_ids_sorted_by_distance; :167-199) are accepted and never touched.
 //
-// MI355X mapping (one block = `epb` consecutive replicas, thread t = agent t % N of
-// local replica t / N; N = 105 -> 3 replicas fill 315 of 320 lanes; the reference
-// geometry block=(N,1,1), grid=(E,1) is simply epb = 1):
-//   phase 0  coalesced [E,N] loads, float32 kinematics (numpy-exact cos/sin), coalesced
-//            stores; post-move state staged in LDS: float32 positions for distances and
-//            the seven observation features per agent as float64 (x,y normalised in
-//            float64, speed/acc/dir normalised in float32 then widened -- exactly the
-//            reference's dtype flow, so the float64 neighbour difference is bit-exact).
-//   phase 1  K nearest neighbours, ~28 VALU ops per candidate instead of a 50-op sorted
-//            insertion:
-//              A. stream all N candidates from LDS (wave-uniform address: broadcast) and
-//                 keep only the K+1 smallest SQUARED distances in registers with a
-//                 v_med3_f32 chain (B[k] = med3(B[k-1], B[k], d2): one op per slot, no
-//                 compares, no ids, no serial dependency);
-//              B. B[K] bounds the K-th neighbour.  Convert it to the float32 distance S
-//                 the reference compares (sqrt rounds, so a RANGE [T2lo, T2hi] of squared
-//                 distances maps to S), stream the candidates again and append the ones
-//                 below the range, plus the first few inside it in id order, to a
-//                 K-entry list in LDS -- exactly the reference's K smallest (distance, id)
-//                 keys;
-//              C. sort those <= K entries by (sqrt(d2), id) with a register sorting
-//                 network and leave the ids in LDS.
-//   phase 2  the packed replicas' observation block is contiguous in HBM ([E,N,F]); it
-//            is produced by a block-strided gather from LDS -- every store instruction
-//            writes 64 consecutive floats (the reference writes one 284-byte-strided row
-//            per thread); (feature, slot) of a column comes from a small LDS table and
-//            the (replica, agent, column) counters advance incrementally: no divisions.
-//   phase 3  rewards: each runner scans the taggers (first minimum wins), tag counts go
-//            through LDS atomics, float adds are replayed in the CPU's order.
+// Two implementations share the move / reward code:
+//
+//   tc_fast_impl<KMAX>   N <= 128 agents per replica, K <= KMAX <= 32 observed neighbours
+//     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>).
+//     block = `epb` whole replicas (105 agents -> 1 replica on 128 threads), thread = agent.
+//       fetch    (fused tick) every global input of the trip is issued first: 7 state words per
+//                agent into registers, each wavefront's rows of the two probability tensors
+//                straight into LDS (global_load_lds_dwordx4, 1 KiB per instruction);
+//       sample   (fused tick) Philox4x32-10 + inverse CDF on a running float32 sum, both heads;
+//       move     float32 kinematics exactly as numpy evaluates them (numpy-exact cos/sin);
+//                post-move state staged in LDS (positions; 32-byte feature records);
+//       tags     every runner finds its nearest tagger; tag counts through LDS atomics (their
+//                block barrier is the one after the neighbour phase);
+//       search   per agent, in registers: (A) the K+1 smallest squared distances with a
+//                v_med3_f32 chain; (B) one 128-bit mask "d^2 <= the K-th" built with
+//                v_cmp + v_addc (ties at the float32-sqrt cut resolved exactly as the stable
+//                heapq.nsmallest does); (C) the <= K set bits peeled in id order and sorted by
+//                (sqrt(d^2), id) with a Batcher network;
+//       gather   each WAVEFRONT turns the rows of its own 64 agents into observation rows inside a
+//                private LDS staging buffer, a chunk of rows at a time, and streams every chunk out
+//                as one contiguous run of 16-byte stores (the [E, N, F] layout makes a replica's
+//                rows contiguous); no block barrier between search and gather, so a wavefront's
+//                stores overlap the other wavefronts' search.  nearest_neighbor_ids leaves through
+//                the same staging buffer;
+//       rewards  tag counts -> rewards in the CPU's add order, done flags;
+//       reset    (fused tick) finished replicas are restored in place from the registered
+//                `*_at_reset` copies.
+//
+//   tc_generic_impl      any N <= 1024, any K, full observations (entry points
+//     HipTagContinuousStep / HipTagContinuousTick): K-pass selection per agent, observation
+//     rows written from a block-strided (row, slot) loop (16-byte stores in the
+//     full-observation mode).
 #include "wd_common.h"
 
-// Timing experiments only (scripts/ablate_tc.sh): bit 0 skips phase 1 (neighbour search),
-// bit 1 skips phase 2 (observation gather), bit 2 stops phase 1 after part A, bit 3 after
-// part B.  Results are wrong when any bit is set; the shipped code object uses 0.
-#ifndef WD_TC_ABLATE
-#define WD_TC_ABLATE 0
-#endif
-// -DWD_TC_PROFILE: thread 0 of every block stores s_memtime stamps at the phase boundaries into
-// the (otherwise unused) neighbor_distances array, 16 x uint64 per block (scripts/phase_profile.py).
-#ifdef WD_TC_PROFILE
-#define WD_TC_STAMP(slot) do { if (threadIdx.x == 0 && l.prof) { l.prof[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
-    if ((slot) == 0) l.prof[blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime(); \
-    if ((slot) == 10) l.prof[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define WD_TC_STAMP(slot) do { } while (0)
-#endif
-
-// Start cohorts (see tc_step_impl): number of cohorts, block-id shift that selects the cohort,
-// start offset between consecutive cohorts in ns.
-#ifndef WD_TC_COHORTS
-#define WD_TC_COHORTS 1
-#endif
-#ifndef WD_TC_COHORT_SHIFT
-#define WD_TC_COHORT_SHIFT 8
-#endif
-#ifndef WD_TC_COHORT_NS
-#define WD_TC_COHORT_NS 4000
-#endif
-
-// Store policy of the observation rows (timing experiments: scripts/store_policy_tc.sh).
-// 0 = plain write-back stores, 1 = non-temporal, 2 = system-scope, 3 = agent-scope write-through.
-#ifndef WD_TC_OBS_STORE
-#define WD_TC_OBS_STORE 0
-#endif
-
 namespace {
-
-__device__ __forceinline__ void tc_store_obs(float *p, float v) {
-#if WD_TC_OBS_STORE == 1
-  __builtin_nontemporal_store(v, p);
-#elif WD_TC_OBS_STORE == 2
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#elif WD_TC_OBS_STORE == 3
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  *p = v;
-#endif
-}
 
 struct TcArgs {
   float *loc_x, *loc_y, *speed, *direction, *acceleration;
@@ -112,16 +69,10 @@ struct TcArgs {
   int *done, *timestep;
   int N, T, E;
   int env_begin;  // first replica of this launch (a launch covers replicas [env_begin, E))
-  unsigned long long *prof;  // phase time stamps (profiling builds only)
-};
-
-struct TcCand {
-  float d2;
-  int id;
 };
 
 // extra inputs of the fused rollout tick (sample both action heads -> step -> reset finished
-// replicas, ONE launch; see HipTagContinuousTick below)
+// replicas, ONE launch)
 struct TcResetEntry {  // same layout as wd_reset_entry in wd_core.hip
   uint32_t *data;
   const uint32_t *ref;
@@ -141,87 +92,47 @@ struct TcFuse {
 // observation features of one agent after the move, as the reference computes them (:453-470):
 // x, y normalised in float64; speed / acceleration / direction normalised in float32 (widened
 // to float64 only for the neighbour difference); type and still_in_game packed in one word.
-// 48 bytes = three 16-byte slots, so a neighbour is fetched with two ds_read_b128.
+// 32 bytes: a neighbour is fetched with two ds_read_b128.
 struct __attribute__((aligned(16))) TcFeat {
   double nx, ny;
   float nsp, nac, ndir;
   int type_sig;  // bit 0: agent type (1 = tagger), bit 1: still_in_the_game before tagging
-  int pad_[2];
 };
 
-// LDS carve-up for `epb` packed replicas, A = epb * N agents (offsets multiples of 8).
-struct TcLds {
-  TcFeat *feat;      // [A] observation features (see TcFeat)
-  TcCand *cand;      // [A][K+1] phase-1 lists; afterwards the first K ints of a row = neighbour ids
-  float2 *xy;        // [A] positions after the move (x = +BIG for agents out of the game)
-  int *sig;          // [A] still_in_the_game before this tick's tagging
-  int *tagcnt;       // [A] tags credited to a tagger this tick
+struct TcCand {
+  float d2;
+  int id;
+};
+
+#define WD_TC_TAB 64      // capacity of the LDS copies of the action tables
+#define WD_BIG 1.0e30f    // (x - BIG)^2 overflows to +inf: such a candidate is never selected
+
+__device__ __forceinline__ size_t tc_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// replica-independent tables, alive for the whole launch
+struct TcTables {
   int *types;        // [N]
   int *tagger_ids;   // [N] ascending
-  float *acc_tab, *turn_tab;  // action tables (n_acc, n_turn entries; capacity 64 each)
+  float *acc_tab, *turn_tab;  // action tables (n_acc, n_turn entries; capacity WD_TC_TAB each)
   int *wave_cnt;     // [16] taggers per wavefront (rank computation)
   int *tstep, *nrun; // [epb]
   float *tfrac;      // [epb] float(t) / episode_length
   int *doneflag;     // [epb] replica finished on this tick (fused tick only)
-  unsigned long long *prof;
 };
 
-#define WD_TC_TAB 64  // capacity of the LDS copies of the action tables
-
-__device__ __forceinline__ size_t tc_align16(size_t v) { return (v + 15) & ~(size_t)15; }
-
-// The per-trip work area (features, lists, positions, flags) doubles as the two probability slabs
-// of the fused tick, which are dead before phase 0 writes it: min_area_bytes = both slabs.
-__device__ __forceinline__ TcLds tc_carve(unsigned char *p0, int epb, int N, int K, size_t min_area_bytes) {
-  // offsets only (no pointer differences: they turn LDS pointers into flat ones and back)
-  TcLds l;
-  const size_t A = (size_t)epb * N;
+__device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, int N) {
+  TcTables t;
   size_t off = 0;
-  l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
-  l.cand = (TcCand *)(p0 + off); off += tc_align16(8 * A * (K + 1));
-  l.xy = (float2 *)(p0 + off); off += 8 * A;
-  l.sig = (int *)(p0 + off); off += 4 * A;
-  l.tagcnt = (int *)(p0 + off); off += 4 * A;
-  off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
-  l.types = (int *)(p0 + off); off += 4 * (size_t)N;
-  l.tagger_ids = (int *)(p0 + off); off += 4 * (size_t)N;
-  l.acc_tab = (float *)(p0 + off); off += 4 * WD_TC_TAB;
-  l.turn_tab = (float *)(p0 + off); off += 4 * WD_TC_TAB;
-  l.wave_cnt = (int *)(p0 + off); off += 4 * 16;
-  l.tstep = (int *)(p0 + off); off += 4 * epb;
-  l.nrun = (int *)(p0 + off); off += 4 * epb;
-  l.tfrac = (float *)(p0 + off); off += 4 * epb;
-  l.doneflag = (int *)(p0 + off);
-  return l;
-}
-
-// Copy n floats global -> LDS with every thread's loads in flight before the first LDS write
-// (a plain strided copy loop serialises load -> write per trip: ~1 us per trip at 4 waves/SIMD).
-// src needs 4-byte alignment only; 16-byte vector loads are used on the aligned middle part.
-__device__ __forceinline__ void tc_copy_to_lds(float *dst, const float *__restrict__ src, int n, int tid, int T_) {
-  const int head = min(n, (int)(((16u - ((unsigned)(size_t)src & 15u)) & 15u) >> 2));
-  const int nvec = (n - head) >> 2;
-  const int tail0 = head + 4 * nvec;
-  const float4 *v = (const float4 *)(src + head);
-  constexpr int U = 6;  // vector loads kept in flight per thread per round
-  for (int q0 = 0; q0 < nvec; q0 += U * T_) {
-    float4 r[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int q = q0 + u * T_ + tid;
-      if (q < nvec) r[u] = v[q];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int q = q0 + u * T_ + tid;
-      if (q < nvec) {
-        float *d = dst + head + 4 * q;
-        d[0] = r[u].x; d[1] = r[u].y; d[2] = r[u].z; d[3] = r[u].w;
-      }
-    }
-  }
-  if (tid < head) dst[tid] = src[tid];
-  if (tid < n - tail0) dst[tail0 + tid] = src[tail0 + tid];
+  t.types = (int *)(p + off); off += 4 * (size_t)N;
+  t.tagger_ids = (int *)(p + off); off += 4 * (size_t)N;
+  t.acc_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
+  t.turn_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
+  t.wave_cnt = (int *)(p + off); off += 4 * 16;
+  t.tstep = (int *)(p + off); off += 4 * epb;
+  t.nrun = (int *)(p + off); off += 4 * epb;
+  t.tfrac = (float *)(p + off); off += 4 * epb;
+  t.doneflag = (int *)(p + off);
+  return t;
 }
 
 // ---- fused tick: probability slab of ONE wavefront.  The rows of a wavefront's 64 agents are one
@@ -229,9 +140,7 @@ __device__ __forceinline__ void tc_copy_to_lds(float *dst, const float *__restri
 // global address, LDS destination = wave-uniform base + lane*16; dword-aligned sources are enough),
 // 1 KiB per instruction, fully coalesced, no staging registers, asynchronous until the
 // `s_waitcnt vmcnt(0)` before the rows are read back (stride n dwords).  Producer and consumer are
-// the same wavefront: no block barrier.  A per-thread row walk instead costs 2n uncoalesced load
-// instructions per thread, each touching 64 rows (measured: 13 k of the tick's 74 k cycles).
-struct __attribute__((packed, aligned(4))) TcF4u { float x, y, z, w; };  // 16-byte access, dword aligned
+// the same wavefront: no block barrier.
 #define WD_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define WD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 __device__ __forceinline__ void tc_slab_fetch(float *dst, const float *__restrict__ src, int cnt, int lane) {
@@ -271,7 +180,7 @@ __device__ __forceinline__ int tc_slab_sample(const float *row, int n, float u) 
 
 // every global input of one loop trip; issued together so the HBM latency is paid once
 struct TcIn {
-  int sg;
+  int sg, type;
   float dir, acc, speed, x, y, skill;
   int2 sampled;
   uint32_t epoch;
@@ -285,7 +194,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
   const int env = env0 + el;
   const bool active = (el < epb) && (env < a.E);
   const int gi = env * N + ag;
-  in.sg = 0; in.dir = in.acc = in.speed = in.x = in.y = in.skill = 0.f;
+  in.sg = 0; in.type = 0; in.dir = in.acc = in.speed = in.x = in.y = in.skill = 0.f;
   in.sampled = make_int2(0, 0);
   in.epoch = 0u;
   if (active) {
@@ -296,6 +205,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
     in.x = a.loc_x[gi];
     in.y = a.loc_y[gi];
     in.skill = a.skill_levels[ag];
+    in.type = a.agent_types[ag];
     if (!FUSED) in.sampled = ((const int2 *)a.actions)[gi];
     if (FUSED) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
   }
@@ -310,7 +220,204 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
   }
 }
 
-#define WD_BIG 1.0e30f  // (x - BIG)^2 overflows to +inf: such a candidate is never selected
+// ---- replica-independent tables: agent types, ascending tagger list, action tables.
+// Returns the number of taggers.  Ends WITHOUT a barrier: the caller's next barrier publishes them.
+__device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs &a, int N, int n_acc, int n_turn,
+                                               bool tab_in_lds) {
+  const int tid = threadIdx.x, T_ = blockDim.x;
+  if (tab_in_lds) {
+    for (int i = tid; i < n_acc; i += T_) tb.acc_tab[i] = a.acc_actions[i];
+    for (int i = tid; i < n_turn; i += T_) tb.turn_tab[i] = a.turn_actions[i];
+  }
+  int n_taggers = 0;
+  // rank of a tagger = number of taggers with a smaller id: wave ballots + per-wave counts
+  const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
+  if (N <= T_) {  // usual case: one barrier
+    const int ty = (tid < N) ? a.agent_types[tid] : 0;
+    if (tid < N) tb.types[tid] = ty;
+    const unsigned long long m = __ballot(ty == 1);
+    if (lane == 0) tb.wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int w2 = 0; w2 < n_waves; ++w2) {
+      const int c = tb.wave_cnt[w2];
+      before += (w2 < wave) ? c : 0;
+      n_taggers += c;
+    }
+    if (ty == 1) tb.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+  } else {
+    for (int base = 0; base < N; base += T_) {
+      const int i = base + tid;
+      const int ty = (i < N) ? a.agent_types[i] : 0;
+      if (i < N) tb.types[i] = ty;
+      const unsigned long long m = __ballot(ty == 1);
+      if (lane == 0) tb.wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int before = n_taggers;
+      for (int w2 = 0; w2 < wave; ++w2) before += tb.wave_cnt[w2];
+      if (ty == 1) tb.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      for (int w2 = 0; w2 < n_waves; ++w2) n_taggers += tb.wave_cnt[w2];
+      __syncthreads();
+    }
+  }
+  return n_taggers;
+}
+
+// ---- fused tick: sample both action heads for this thread's agent (replaces two sample_actions
+// launches, random.cu:51-85): inverse CDF on a running float32 sum, one Philox call for both heads.
+__device__ __forceinline__ int2 tc_sample_heads(const TcFuse &fz, const TcIn &in, bool active, int gi, int li,
+                                                const float *slab_acc, const float *slab_turn, int n_acc,
+                                                int n_turn) {
+  int2 sampled = make_int2(0, 0);
+  wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
+  if (active) {
+    fz.rng_state[WD_RNG_HEADER + gi] = in.epoch + 1u;
+    rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, in.epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
+                           fz.rng_state[1]);
+  }
+  // every global_load_lds of this wavefront has landed once its vmcnt drains; the rows a lane
+  // reads were all fetched by its own wavefront
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (active) {
+    sampled.x = tc_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
+    sampled.y = tc_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
+    ((int2 *)fz.actions_out)[gi] = sampled;
+  }
+  return sampled;
+}
+
+// ---- move: float32 kinematics exactly as numpy evaluates update_state (:339-401); stores the new
+// state, returns the post-move position, the edge penalty and the observation features.
+struct TcMoved {
+  float x, y, edge_pen;
+  TcFeat ft;
+};
+__device__ __forceinline__ TcMoved tc_move(const TcArgs &a, const TcTables &tb, const TcIn &in, int2 act, int gi,
+                                           bool tab_in_lds) {
+  const float two_pi = 6.2831854820251465f;            // float32(2*pi), :356
+  const float L = a.grid_length;
+  const double diag = (double)L * 1.4142135623730951;  // float32 L * np.sqrt(2) -> f64, :146
+  const float sp_div = a.max_speed + 1.0e-10f;         // float32 + float32(eps), :456
+  const float s = (float)in.sg;
+  // (value select, not pointer select: a pointer that may be LDS or global becomes a flat access)
+  float d_acc = tb.acc_tab[min(act.x, WD_TC_TAB - 1)], d_turn = tb.turn_tab[min(act.y, WD_TC_TAB - 1)];
+  asm volatile("" : "+v"(d_acc), "+v"(d_turn));  // keeps the two loads from being merged into one flat load
+  if (!tab_in_lds) {
+    d_acc = a.acc_actions[act.x];
+    d_turn = a.turn_actions[act.y];
+  }
+  const float dir = wd_np_remainderf(in.dir + d_turn, two_pi) * s;            // :355-357
+  float acc = in.acc + d_acc;                                                 // :359
+  const float vmax = a.max_speed * in.skill;                                  // :363
+  float v = in.speed + acc;
+  v = fminf(fmaxf(v, 0.0f), vmax) * s;                                        // :364-366
+  acc = acc * (v > 0.0f ? 1.0f : 0.0f) * (v < vmax ? 1.0f : 0.0f);            // :367
+  float sn, cs;
+  wd_np_sincosf(dir, sn, cs);
+  float px = in.x + v * cs;                                                   // :369-374
+  float py = in.y + v * sn;
+  const bool crossed = !((px >= 0.0f) && (px <= L) && (py >= 0.0f) && (py <= L));
+  px = fminf(fmaxf(px, 0.0f), L);                                             // :385-391
+  py = fminf(fmaxf(py, 0.0f), L);
+  TcMoved m;
+  m.edge_pen = a.edge_hit_penalty * (crossed ? 1.0f : 0.0f);                  // :394
+  a.loc_x[gi] = px;
+  a.loc_y[gi] = py;
+  a.speed[gi] = v;
+  a.direction[gi] = dir;
+  a.acceleration[gi] = acc;
+  a.edge_pen_arr[gi] = m.edge_pen;
+  m.x = px;
+  m.y = py;
+  m.ft.nx = (double)px / diag;    // :462 (float64 division)
+  m.ft.ny = (double)py / diag;
+  m.ft.nsp = v / sp_div;          // float32 division (:456-458)
+  m.ft.nac = acc / sp_div;
+  m.ft.ndir = dir / two_pi;
+  m.ft.type_sig = (in.type & 1) | (in.sg ? 2 : 0);
+  return m;
+}
+
+// ---- the seven observation values of row `me` about neighbour `nb` (:479-560).  float64
+// differences for x, y, narrowed to float32 like the reference's device push; speed / acc / dir:
+// the reference widens float32 values and subtracts in float64; for float32 operands that rounds
+// to exactly the float32 difference (53 >= 2*24+2 bits: double rounding is innocuous).
+__device__ __forceinline__ void tc_obs_values(float (&vals)[7], const TcFeat &nb, const TcFeat &me, bool rel,
+                                              bool valid) {
+  vals[0] = rel ? (float)(nb.nx - me.nx) : 0.0f;
+  vals[1] = rel ? (float)(nb.ny - me.ny) : 0.0f;
+  vals[2] = rel ? (nb.nsp - me.nsp) : 0.0f;
+  vals[3] = rel ? (nb.nac - me.nac) : 0.0f;
+  vals[4] = rel ? (nb.ndir - me.ndir) : 0.0f;
+  vals[5] = valid ? (float)(nb.type_sig & 1) : 0.0f;
+  vals[6] = valid ? (float)((nb.type_sig >> 1) & 1) : 0.0f;
+}
+
+// ---- tags: a runner in the game finds its nearest tagger (ascending ids, first minimum wins,
+// :643-651) and is tagged when closer than the margin (:661); counts go through LDS atomics.
+__device__ __forceinline__ bool tc_find_tag(const TcArgs &a, const TcTables &tb, const float2 *cxy, int *tagcnt_env,
+                                            int *nrun_env, int n_taggers, float my_x, float my_y) {
+  float best = __builtin_inff();
+  int bt = -1;
+  for (int t = 0; t < n_taggers; ++t) {
+    const int j = tb.tagger_ids[t];
+    const float2 pt = cxy[j];  // taggers are never out of the game: real positions
+    const float dx = my_x - pt.x, dy = my_y - pt.y;
+    const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
+    if (d < best) { best = d; bt = j; }
+  }
+  if (bt >= 0 && best < a.margin) {
+    atomicAdd(&tagcnt_env[bt], 1);
+    if (a.runner_exits) atomicSub(nrun_env, 1);
+    return true;
+  }
+  return false;
+}
+
+// ---- rewards / done of one agent (:655-678, :880-883); call after the barrier that follows the tags
+__device__ __forceinline__ void tc_finish_agent(const TcArgs &a, const TcTables &tb, int el, int ag, int gi, int env,
+                                                int sg, bool is_runner, bool tagged, int tagcnt, float edge_pen,
+                                                bool fused) {
+  float rew = 0.0f;
+  if (sg) { rew += edge_pen; rew += a.step_rewards[ag]; }       // :655-658
+  if (tagged) rew += a.tag_penalty;                             // :664
+  for (int k = 0; k < tagcnt; ++k) rew += a.tag_reward;         // :665, one add per tag
+  const bool still_runner = is_runner && !(tagged && a.runner_exits);
+  if (tb.tstep[el] == a.T && still_runner) rew += a.end_reward; // :674-676
+  a.rewards[gi] = rew;
+  if (tagged && a.runner_exits) a.sig_arr[gi] = 0;              // :669
+  if (ag == 0) {
+    const int nr = tb.nrun[el];
+    a.num_runners[env] = nr;
+    const bool fin = (tb.tstep[el] >= a.T || nr == 0);          // :880-883
+    if (fin) a.done[env] = 1;
+    if (fused) tb.doneflag[el] = fin ? 1 : 0;
+  }
+}
+
+// ---- fused tick: reset finished replicas in place (reset.cu:9-75 for every registered array).
+// `_done_` stays 1 so the trainer can read which replicas finished on this tick; the next tick
+// clears it.  Must be entered by the whole block after a barrier that follows every store of the
+// tick to these rows (the caller drains its own stores first).
+__device__ __forceinline__ void tc_reset_finished(const TcArgs &a, const TcFuse &fz, const TcTables &tb, int env0,
+                                                  int epb) {
+  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int envs_here = min(epb, a.E - env0);
+  for (int e = 0; e < envs_here; ++e) {
+    if (tb.doneflag[e] == 0) continue;  // block-uniform
+    for (int r = 0; r < fz.n_reset_arrays; ++r) {
+      const TcResetEntry ent = fz.reset_table[r];
+      const long base = (long)(env0 + e) * ent.row_elems;
+      for (int i = tid; i < ent.row_elems; i += T_) ent.data[base + i] = ent.ref[base + i];
+    }
+    if (tid == 0) a.timestep[env0 + e] = 0;
+  }
+}
+
+// =====================================================================================
+//                   fast path: N <= 128, partial observations, K <= KMAX
+// =====================================================================================
 
 // compare-exchange of (distance, id) keys, ascending.  distance >= 0, so its float bits order
 // like an unsigned integer and (bits << 32 | id) is one total 64-bit key.
@@ -357,37 +464,37 @@ __device__ __forceinline__ void tc_sort_network(unsigned long long (&key)[n]) {
   for (int c = 0; c < net.count; ++c) tc_cex(key[net.a[c]], key[net.b[c]]);
 }
 
-// ---- phase 1, register-resident variant (K <= KMAX) --------------------------------
+// K nearest neighbours of agent `ag` among the N <= 128 agents of its replica, entirely in
+// registers.  cxy = the replica's post-move positions in LDS (x = +BIG for agents out of the game).
+// Result: nid[k], k < K = neighbour ids in the reference's order (float32 distance, then id;
+// -1 = fewer than k+1 candidates in the game).
 template <int KMAX>
-__device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag, int li, int N, int K) {
-  const float2 *cxy = l.xy + el * N;
-  TcCand *mine = l.cand + (size_t)li * (K + 1);
+__device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX]) {
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   const float INF = __builtin_inff();
 
   // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
-  //    agents out of the game contribute +inf)
+  //    agents out of the game contribute +inf): B[k] = med3(B[k-1], B[k], d2), one op per slot,
+  //    no compares, no ids
   float B[KMAX + 1];
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) B[k] = INF;
   for (int j = 0; j < N; ++j) {
-    const float2 pj = cxy[j];
+    const float2 pj = cxy[j];  // wave-uniform address: broadcast
     const float dx = xi - pj.x, dy = yi - pj.y;
     const float d2 = dx * dx + dy * dy;
 #pragma unroll
     for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], d2);
     B[0] = fminf(B[0], d2);
   }
-  if (WD_TC_ABLATE & 4) { ((float *)mine)[0] = B[KMAX]; return; }
-#ifdef WD_TC_PROFILE
-  if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 4] = __builtin_readcyclecounter();
-#endif
   // B[k], k = 1..K are the K smallest squared distances to OTHER agents (B[0] is self or a
   // co-located twin).  T2 = the K-th of them.
   float T2 = INF;
 #pragma unroll
   for (int k = 1; k <= KMAX; ++k) T2 = (k == K) ? B[k] : T2;
-  // range of squared distances whose float32 sqrt equals S = sqrtf(T2)
+  // The reference orders by float32 sqrt distance and breaks ties by id (heapq.nsmallest is stable,
+  // :435-437).  sqrt rounds, so a RANGE [T2lo, T2hi] of squared distances maps to the K-th distance
+  // S = sqrtf(T2); it is derived exactly in float64 from the midpoints around S.
   float T2lo, T2hi;
   if (T2 == INF) {          // fewer than K candidates in the game: take them all
     T2lo = INF; T2hi = 3.0e38f;
@@ -406,159 +513,354 @@ __device__ __forceinline__ void tc_knn_registers(const TcLds &l, int el, int ag,
     T2hi = th;
     T2lo = tl;
   }
-  unsigned long long key[KMAX];
-  if (N <= 128) {
-    // B. second pass: one 128-bit per-lane mask "inside or below the range".  Each candidate costs
-    //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no LDS
-    //    traffic, no data-dependent addressing.  Candidate b of word w lands on bit (nb-1-b):
-    //    undone with one bit-reverse per word.
-    unsigned sel[4] = {0u, 0u, 0u, 0u};
-    int n_upto = 0;
-    // (loop-invariant across trips, but hoisting them costs long-lived registers the kernel does not
-    // have at 128 VGPRs: the empty asm statements pin their computation here)
-    int ag_here = ag, n_here = N;
-    asm volatile("" : "+v"(ag_here));
-    asm volatile("" : "+s"(n_here));
+  // B. second pass: one 128-bit per-lane mask "inside or below the range".  Each candidate costs
+  //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no LDS
+  //    traffic beyond the broadcast read, no data-dependent addressing.  Candidate b of word w lands
+  //    on bit (nb-1-b): undone with one bit-reverse per word.
+  unsigned sel[4] = {0u, 0u, 0u, 0u};
+  int n_upto = 0;
+  // (loop-invariant across trips, but hoisting them costs long-lived registers the kernel does not
+  // have at 128 VGPRs: the empty asm statements pin their computation here)
+  int ag_here = ag, n_here = N;
+  asm volatile("" : "+v"(ag_here));
+  asm volatile("" : "+s"(n_here));
+#define WD_TC_PUSH(m, d2v, thr, op) \
+  asm("v_cmp_" op "_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(thr) : "vcc")
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int j0 = 32 * w;
+    if (j0 < n_here) {  // wave-uniform
+      const int nb = min(32, n_here - j0);
+      unsigned mu = 0u;
+      // unrolled by hand (loops holding inline asm are not unrolled by the compiler) so the four
+      // LDS reads of a group are in flight together
+      int b = 0;
+      for (; b + 4 <= nb; b += 4) {
+        const float2 p0 = cxy[j0 + b], p1 = cxy[j0 + b + 1], p2 = cxy[j0 + b + 2], p3 = cxy[j0 + b + 3];
+        const float ax = xi - p0.x, ay = yi - p0.y, bx = xi - p1.x, by = yi - p1.y;
+        const float cx = xi - p2.x, cy = yi - p2.y, ex = xi - p3.x, ey = yi - p3.y;
+        const float d0 = ax * ax + ay * ay, d1 = bx * bx + by * by, d2 = cx * cx + cy * cy, d3 = ex * ex + ey * ey;
+        WD_TC_PUSH(mu, d0, T2hi, "le");
+        WD_TC_PUSH(mu, d1, T2hi, "le");
+        WD_TC_PUSH(mu, d2, T2hi, "le");
+        WD_TC_PUSH(mu, d3, T2hi, "le");
+      }
+      for (; b < nb; ++b) {
+        const float2 pj = cxy[j0 + b];
+        const float dx = xi - pj.x, dy = yi - pj.y;
+        const float d2 = dx * dx + dy * dy;
+        WD_TC_PUSH(mu, d2, T2hi, "le");
+      }
+      const unsigned self_bit = ((ag_here >> 5) == w) ? (1u << (ag_here & 31)) : 0u;
+      sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
+      n_upto += __popc(sel[w]);
+    }
+  }
+  // Usually exactly K others are inside or below the range and the mask is the answer.  More
+  // than K means several candidates share the K-th float32 distance: the reference keeps the
+  // lowest ids among them.  Rare (a float32 sqrt tie at the cut), so the "strictly below" mask is
+  // only built then.
+  if (n_upto > K) {
+    unsigned lo[4] = {0u, 0u, 0u, 0u};
+    int c_less = 0;  // others strictly below the range
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int j0 = 32 * w;
-      if (j0 < n_here) {  // wave-uniform
+      if (j0 < n_here) {
         const int nb = min(32, n_here - j0);
-        unsigned mu = 0u;
-        // m = 2m + (d2 <= T2hi): compare into VCC, add with carry-in (2 VALU ops per candidate).
-        // Unrolled by hand (loops holding inline asm are not unrolled by the compiler) so the four
-        // LDS reads of a group are in flight together.
-#define WD_TC_PUSH(m, d2v, thr, op) \
-  asm("v_cmp_" op "_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(thr) : "vcc")
-        int b = 0;
-        for (; b + 4 <= nb; b += 4) {
-          const float2 p0 = cxy[j0 + b], p1 = cxy[j0 + b + 1], p2 = cxy[j0 + b + 2], p3 = cxy[j0 + b + 3];
-          const float ax = xi - p0.x, ay = yi - p0.y, bx = xi - p1.x, by = yi - p1.y;
-          const float cx = xi - p2.x, cy = yi - p2.y, ex = xi - p3.x, ey = yi - p3.y;
-          const float d0 = ax * ax + ay * ay, d1 = bx * bx + by * by, d2 = cx * cx + cy * cy, d3 = ex * ex + ey * ey;
-          WD_TC_PUSH(mu, d0, T2hi, "le");
-          WD_TC_PUSH(mu, d1, T2hi, "le");
-          WD_TC_PUSH(mu, d2, T2hi, "le");
-          WD_TC_PUSH(mu, d3, T2hi, "le");
-        }
-        for (; b < nb; ++b) {
+        unsigned mb = 0u;
+        for (int b = 0; b < nb; ++b) {
           const float2 pj = cxy[j0 + b];
           const float dx = xi - pj.x, dy = yi - pj.y;
           const float d2 = dx * dx + dy * dy;
-          WD_TC_PUSH(mu, d2, T2hi, "le");
+          WD_TC_PUSH(mb, d2, T2lo, "lt");
         }
-        const unsigned self_bit = ((ag_here >> 5) == w) ? (1u << (ag_here & 31)) : 0u;
-        sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
-        n_upto += __popc(sel[w]);
+        lo[w] = (__brev(mb) >> (32 - nb)) & sel[w];
+        c_less += __popc(lo[w]);
       }
     }
-    // Usually exactly K others are inside or below the range and the mask is the answer.  More
-    // than K means several candidates share the K-th float32 distance: the reference keeps the
-    // lowest ids among them (stable heapq.nsmallest, :435-437).  Rare (a float32 sqrt tie at the
-    // cut), so the "strictly below" mask is only built then.
-    if (n_upto > K) {
-      unsigned lo[4] = {0u, 0u, 0u, 0u};
-      int c_less = 0;  // others strictly below the range
+    int quota = K - c_less;  // members of the range still to take, ascending id
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int j0 = 32 * w;
-        if (j0 < n_here) {
-          const int nb = min(32, n_here - j0);
-          unsigned mb = 0u;
-          for (int b = 0; b < nb; ++b) {
-            const float2 pj = cxy[j0 + b];
-            const float dx = xi - pj.x, dy = yi - pj.y;
-            const float d2 = dx * dx + dy * dy;
-            WD_TC_PUSH(mb, d2, T2lo, "lt");
-          }
-          lo[w] = (__brev(mb) >> (32 - nb)) & sel[w];
-          c_less += __popc(lo[w]);
-        }
+    for (int w = 0; w < 4; ++w) {
+      unsigned tie = sel[w] & ~lo[w];
+      const int have_t = __popc(tie);
+      if (have_t > quota) {  // keep the lowest `quota` set bits
+        unsigned kept = 0u;
+        for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
+        tie = kept;
       }
-      int quota = K - c_less;  // members of the range still to take, ascending id
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        unsigned tie = sel[w] & ~lo[w];
-        const int have_t = __popc(tie);
-        if (have_t > quota) {  // keep the lowest `quota` set bits
-          unsigned kept = 0u;
-          for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
-          tie = kept;
-        }
-        quota -= min(have_t, quota);
-        sel[w] = lo[w] | tie;
-      }
-    }
-    if (WD_TC_ABLATE & 8) { ((unsigned *)mine)[0] = sel[0] ^ sel[1] ^ sel[2] ^ sel[3]; return; }
-#ifdef WD_TC_PROFILE
-    if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 5] = __builtin_readcyclecounter();
-#endif
-    // C. peel the (at most K) ids off the mask in ascending order, rebuild their distances
-    //    and form 64-bit keys (float bits of sqrt(d2) << 32 | id)
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const int which = sel[0] ? 0 : sel[1] ? 1 : sel[2] ? 2 : sel[3] ? 3 : 4;
-      const unsigned cur = sel[0] ? sel[0] : sel[1] ? sel[1] : sel[2] ? sel[2] : sel[3];
-      const bool have = which < 4;
-      const int j = have ? which * 32 + (__ffs(cur) - 1) : ag;
-      const unsigned cleared = cur & (cur - 1u);
-      sel[0] = (which == 0) ? cleared : sel[0];
-      sel[1] = (which == 1) ? cleared : sel[1];
-      sel[2] = (which == 2) ? cleared : sel[2];
-      sel[3] = (which == 3) ? cleared : sel[3];
-      const float2 pj = cxy[j];
-    const float dx = xi - pj.x, dy = yi - pj.y;
-      const unsigned long long sbits =
-          have ? (unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000ull;
-      key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? j : 0xffff);
-    }
-  } else {
-    // B'. more than 128 agents: same selection, collected in a (K+1)-slot LDS row.  Branch-free:
-    //     every candidate is written to the next free slot and the slot only advances when it
-    //     was selected (the write after the K-th selection stays inside the row).
-    int c_less = 0;  // others strictly below the range (counting pre-pass)
-    for (int j = 0; j < N; ++j) {
-      const float2 pc = cxy[j];
-      const float dx = xi - pc.x, dy = yi - pc.y;
-      c_less += (j != ag && (dx * dx + dy * dy) < T2lo) ? 1 : 0;
-    }
-    const int need_tie = K - c_less;
-    int cnt = 0, tie_taken = 0;
-    for (int j = 0; j < N; ++j) {
-      const float2 pj = cxy[j];
-    const float dx = xi - pj.x, dy = yi - pj.y;
-      const float d2 = dx * dx + dy * dy;
-      const bool other = (j != ag);
-      const bool less = other && (d2 < T2lo);
-      const bool tie = other && !less && (d2 <= T2hi) && (tie_taken < need_tie);
-      mine[cnt] = TcCand{d2, j};
-      cnt += (less || tie) ? 1 : 0;
-      tie_taken += tie ? 1 : 0;
-    }
-    if (WD_TC_ABLATE & 8) return;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const bool have = k < cnt;
-      const TcCand c = mine[have ? k : 0];
-      const unsigned long long sbits = have ? (unsigned long long)__float_as_uint(sqrtf(c.d2)) : 0x7f800000ull;
-      key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? c.id : 0xffff);
+      quota -= min(have_t, quota);
+      sel[w] = lo[w] | tie;
     }
   }
-  tc_sort_network<KMAX>(key);
-#ifdef WD_TC_PROFILE
-  if (threadIdx.x == 0 && l.prof) l.prof[blockIdx.x * 16 + 6] = __builtin_readcyclecounter();
-#endif
-  int *out = (int *)mine;
+#undef WD_TC_PUSH
+  // C. peel the (at most K) ids off the mask in ascending order, rebuild their distances
+  //    and form 64-bit keys (float bits of sqrt(d2) << 32 | id), then sort
+  unsigned long long key[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k)
-    if (k < K) out[k] = (key[k] >> 32) == 0x7f800000ull ? -1 : (int)(unsigned int)key[k];
+  for (int k = 0; k < KMAX; ++k) {
+    const int which = sel[0] ? 0 : sel[1] ? 1 : sel[2] ? 2 : sel[3] ? 3 : 4;
+    const unsigned cur = sel[0] ? sel[0] : sel[1] ? sel[1] : sel[2] ? sel[2] : sel[3];
+    const bool have = which < 4;
+    const int j = have ? which * 32 + (__ffs(cur) - 1) : ag;
+    const unsigned cleared = cur & (cur - 1u);
+    sel[0] = (which == 0) ? cleared : sel[0];
+    sel[1] = (which == 1) ? cleared : sel[1];
+    sel[2] = (which == 2) ? cleared : sel[2];
+    sel[3] = (which == 3) ? cleared : sel[3];
+    const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
+    const unsigned long long sbits =
+        have ? (unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000ull;
+    key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? j : 0xffff);
+  }
+  tc_sort_network<KMAX>(key);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) nid[k] = (key[k] >> 32) == 0x7f800000ull ? -1 : (int)(unsigned int)key[k];
 }
 
-// ---- phase 1, generic K: K passes, each picks the smallest (d, id) key above the previous
-__device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, int li, int N, int K) {
-  const float2 *cxy = l.xy + el * N;
-  const int *csig = l.sig + el * N;
-  int *out = (int *)(l.cand + (size_t)li * (K + 1));
+// Stream `n` dwords from a wavefront's staging buffer to global memory as one contiguous run.
+// The producer placed dword i of the run at stage[mis + i], mis = (address of dst / 4) & 3, so the
+// 16-byte vectors of the run are 16-byte aligned in LDS and in memory alike; the <= 3 dwords before
+// the first / after the last aligned vector go out as single dwords.
+__device__ __forceinline__ void tc_flush_run(const float *stage, float *dst, int n, int lane) {
+  const int mis = (int)(((size_t)dst >> 2) & 3);
+  const int head = min(n, (4 - mis) & 3);
+  const int nvec = (n - head) >> 2;
+  const int tail0 = head + 4 * nvec;
+  const float4 *sv = (const float4 *)(stage + mis + head);
+  float4 *dv = (float4 *)(dst + head);
+  for (int q = lane; q < nvec; q += 64) dv[q] = sv[q];
+  if (lane < head) dst[lane] = stage[mis + lane];
+  if (lane < n - tail0) dst[tail0 + lane] = stage[mis + tail0 + lane];
+}
+
+// rows of a wavefront's staging buffer: the host sizes the buffer with the same formula
+// (envs/tag_continuous.py: lds_bytes_fast)
+#define WD_TC_STAGE_TARGET 5400  // bytes of rows per wavefront (19 rows of 71 floats)
+__device__ __forceinline__ int tc_stage_rows(int row_dwords) {
+  return max(1, min(64, WD_TC_STAGE_TARGET / (4 * row_dwords)));
+}
+
+// LDS of the fast path.  The per-trip area doubles as the two probability slabs of the fused tick,
+// which are dead before the move phase writes it.
+struct TcFastLds {
+  TcFeat *feat;          // [A] observation features
+  float2 *xy;            // [A] positions after the move (x = +BIG for agents out of the game)
+  int *sig;              // [A] still_in_the_game before this tick's tagging
+  int *tagcnt;           // [A] tags credited to a tagger this tick
+  unsigned short *ids;   // [A][K] block-local neighbour indices (0xffff = none)
+  float *stage;          // [n_waves][stage_dwords] wave-private staging buffers
+  int stage_dwords;
+  TcTables tb;
+};
+
+__device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, int N, int K, int n_waves,
+                                                   size_t min_area_bytes) {
+  TcFastLds l;
+  const size_t A = (size_t)epb * N;
+  const int F = 7 * K + 1;
+  size_t off = 0;
+  l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
+  l.xy = (float2 *)(p0 + off); off += 8 * A;
+  l.sig = (int *)(p0 + off); off += 4 * A;
+  l.tagcnt = (int *)(p0 + off); off += 4 * A;
+  l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
+  l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F) * F) / 4) + 4;
+  l.stage = (float *)(p0 + off); off += (size_t)4 * l.stage_dwords * n_waves;
+  off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
+  l.tb = tc_carve_tables(p0 + off, epb, N);
+  return l;
+}
+
+template <int KMAX, bool FUSED>
+__device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
+                                             int n_turn) {
+  const int N = a.N, K = a.K;
+  const int F = 7 * K + 1;
+  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int epb = max(1, T_ / N);
+  const int n_waves = (T_ + 63) >> 6, wave = tid >> 6, lane = tid & 63;
+  const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
+  const TcFastLds l = tc_carve_fast(smem, epb, N, K, n_waves,
+                                    FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
+  const TcTables &tb = l.tb;
+  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
+  float *const stage = l.stage + (size_t)wave * l.stage_dwords;
+  const int el = tid / N, ag = tid - el * N;
+  const float invK = 1.0f / (float)K, invN = 1.0f / (float)N;
+
+  // ONE trip per block (the host launches ceil(replicas / epb) blocks): every pointer argument is
+  // used once and dies, which is what keeps the kernel inside 128 VGPRs / 104 SGPRs.
+  // All global loads go out before anything else: the table set-up below (a dependent global load +
+  // barrier) then runs in their shadow.
+  const int env0 = a.env_begin + blockIdx.x * epb;
+  TcIn in;
+  tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
+  const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
+  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds);
+  if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
+
+  const int env = env0 + el;
+  const bool active = (el < epb) && (env < a.E);
+  const int gi = env * N + ag;  // index into [E, N] arrays
+  const int li = tid;           // index into LDS arrays (= el * N + ag)
+  const int agents_here = min(epb, a.E - env0) * N;
+  int2 sampled = in.sampled;
+  if (FUSED) {
+    if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
+    sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
+  }
+  __syncthreads();  // tables are published; every wavefront is done with the slabs
+
+  // ------------------------------------------------------------ move
+  float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
+  const int sg = in.sg;
+  const bool is_runner = active && (in.type == 0) && (sg != 0);  // member of self.runners
+  if (active) {
+    const TcMoved m = tc_move(a, tb, in, sampled, gi, tab_in_lds);
+    edge_pen = m.edge_pen; my_x = m.x; my_y = m.y;
+    // agents out of the game are pushed to +BIG for the neighbour search only; every other
+    // consumer (taggers are never out of the game) reads real positions
+    l.xy[li] = make_float2(sg ? m.x : WD_BIG, m.y);
+    l.feat[li] = m.ft;
+    l.sig[li] = sg;
+    l.tagcnt[li] = 0;
+    if (ag == 0) {
+      const int t = a.timestep[env] + 1;  // :800
+      a.timestep[env] = t;
+      tb.tstep[el] = t;
+      tb.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474
+      tb.nrun[el] = a.num_runners[env];
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------ tags (counts are read after the
+  // barrier that follows the gather)
+  bool tagged = false;
+  if (is_runner)
+    tagged = tc_find_tag(a, tb, l.xy + el * N, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
+
+  // ------------------------------------------------------------ search
+  int nid[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) nid[k] = -1;
+  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * N, ag, N, K, nid);
+
+  // ------------------------------------------------------------ gather (wave-private from here
+  // to the barrier: rows [64*wave, 64*wave + wrows) of the block belong to this wavefront's lanes)
+  const int wrow0 = wave * 64;
+  const int wrows = max(0, min(64, agents_here - wrow0));
+  {
+    // neighbour ids: block-local 16-bit copies for the gather, and the [E, N, K] output through
+    // the staging buffer (rows of K dwords, contiguous over the wavefront's agents)
+    int *const istage = (int *)stage;
+    int *const nb_out = a.nearest_ids + ((long)env0 * N + wrow0) * K;
+    const int rows_per_pass = max(1, min(64, (l.stage_dwords - 4) / K));
+    if (active) {
+      const int ebase = el * N;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) l.ids[(size_t)li * K + k] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
+    }
+    for (int r0 = 0; r0 < wrows; r0 += rows_per_pass) {
+      const int rc = min(rows_per_pass, wrows - r0);
+      const int mis = (int)(((size_t)(nb_out + (long)r0 * K) >> 2) & 3);
+      if (lane >= r0 && lane < r0 + rc) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) istage[mis + (lane - r0) * K + k] = nid[k];
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      tc_flush_run((const float *)istage, (float *)(nb_out + (long)r0 * K), rc * K, lane);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  {
+    // observation rows, R rows per chunk: work item = (row, neighbour slot) -> 7 values at
+    // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run
+    const int R = tc_stage_rows(F);
+    float *const obs_w = a.obs + ((long)env0 * N + wrow0) * F;
+    for (int r0 = 0; r0 < wrows; r0 += R) {
+      const int rc = min(R, wrows - r0);
+      float *const dst = obs_w + (long)r0 * F;
+      const int mis = (int)(((size_t)dst >> 2) & 3);
+      const int items = rc * K;
+      for (int t = lane; t < items; t += 64) {
+        const int r = (int)(((float)t + 0.5f) * invK);  // t / K (exact: the quotient is >= 0.5/K away from an integer)
+        const int k = t - r * K;
+        const int m = wrow0 + r0 + r;                   // block-local row
+        const unsigned j = l.ids[(size_t)m * K + k];
+        const TcFeat me = l.feat[m];
+        const bool in_game = (me.type_sig & 2) != 0;
+        const bool valid = in_game && (j != 0xffffu);
+        const TcFeat nb = l.feat[valid ? j : (unsigned)m];
+        float vals[7];
+        tc_obs_values(vals, nb, me, valid, valid);
+        float *o = stage + mis + r * F + k;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) o[c * K] = vals[c];
+      }
+      if (lane < rc) {
+        // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
+        const int m = wrow0 + r0 + lane;
+        const int e_m = (int)(((float)m + 0.5f) * invN);
+        stage[mis + lane * F + 7 * K] = (l.sig[m] != 0) ? tb.tfrac[e_m] : 0.0f;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      tc_flush_run(stage, dst, rc * F, lane);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();  // every runner's tag is counted
+
+  // ------------------------------------------------------------ rewards / done
+  if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, FUSED);
+  if (FUSED) {
+    __syncthreads();  // doneflag
+    bool any = false;
+    for (int e = 0; e < min(epb, a.E - env0); ++e) any = any || (tb.doneflag[e] != 0);
+    if (any) {  // block-uniform, rare (once per episode)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores are complete ...
+      __syncthreads();                                  // ... before any wavefront rewrites the rows
+      tc_reset_finished(a, fz, tb, env0, epb);
+    }
+  }
+}
+
+// =====================================================================================
+//                generic path: any N <= 1024, any K, full observations
+// =====================================================================================
+struct TcGenLds {
+  TcFeat *feat;      // [A]
+  int *nbr;          // [A][K] neighbour ids (env-local, -1 = none)
+  float2 *xy;        // [A]
+  int *sig;          // [A]
+  int *tagcnt;       // [A]
+  TcTables tb;
+};
+
+__device__ __forceinline__ TcGenLds tc_carve_generic(unsigned char *p0, int epb, int N, int K, size_t min_area_bytes) {
+  TcGenLds l;
+  const size_t A = (size_t)epb * N;
+  size_t off = 0;
+  l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
+  l.nbr = (int *)(p0 + off); off += tc_align16(4 * A * (size_t)max(K, 1));
+  l.xy = (float2 *)(p0 + off); off += 8 * A;
+  l.sig = (int *)(p0 + off); off += 4 * A;
+  l.tagcnt = (int *)(p0 + off); off += 4 * A;
+  off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
+  l.tb = tc_carve_tables(p0 + off, epb, N);
+  return l;
+}
+
+// K passes, each picks the smallest (float32 distance, id) key above the previous one
+__device__ __forceinline__ void tc_knn_generic(const float2 *cxy, const int *csig, int *out, int ag, int N, int K) {
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   float pd = -1.0f;
   int pj = -1;
@@ -583,218 +885,86 @@ __device__ __forceinline__ void tc_knn_generic(const TcLds &l, int el, int ag, i
   }
 }
 
-template <int KMAX, bool FUSED>
-__device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
-                                             int n_turn) {
+struct __attribute__((packed, aligned(4))) TcF4u { float x, y, z, w; };  // 16-byte access, dword aligned
+
+template <bool FUSED>
+__device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
+                                                int n_turn) {
   const int N = a.N, K = a.use_full_obs ? 0 : a.K;
   const int W = a.use_full_obs ? (N - 1) : K;  // columns per feature
   const int F = 7 * W + 1;
-  const int epb = max(1, (int)blockDim.x / N);
-  const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
-  const TcLds l = tc_carve(smem, epb, N, K,
-                           FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
-  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
   const int tid = threadIdx.x, T_ = blockDim.x;
+  const int epb = max(1, T_ / N);
+  const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
+  const TcGenLds l = tc_carve_generic(smem, epb, N, K,
+                                      FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
+  const TcTables &tb = l.tb;
+  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
   const int el = tid / N, ag = tid - el * N;
-  // (profiling builds: a launch over replicas [env_begin, E) stamps the rows of its own blocks)
-  const_cast<TcLds &>(l).prof = a.prof ? a.prof + (size_t)(a.env_begin / epb) * 16 : nullptr;
-  const int row_ints = 2 * (K + 1);                    // ints per agent row of the id list
-  const float two_pi = 6.2831854820251465f;            // float32(2*pi), :356
-  const float L = a.grid_length;
-  const double diag = (double)L * 1.4142135623730951;  // float32 L * np.sqrt(2) -> f64, :146
-  const float sp_div = a.max_speed + 1.0e-10f;         // float32 + float32(eps), :456
 
-#if WD_TC_COHORTS > 1
-  // Start cohort: blocks of different cohorts begin WD_TC_COHORT_NS apart, so that the memory-bound
-  // phases (probability fetch, observation stores) of one cohort run under the VALU-bound neighbour
-  // search of another instead of all blocks marching through the phases in lock step.
-  {
-    const unsigned cohort = (blockIdx.x >> WD_TC_COHORT_SHIFT) % WD_TC_COHORTS;
-    if (cohort) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long wait = (unsigned long long)cohort * (WD_TC_COHORT_NS / 10);
-      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(2);
-    }
-  }
-#endif
-  WD_TC_STAMP(0);
-  // the first trip's global loads go out before anything else: the table set-up below (a
-  // dependent global load + barrier) then runs in their shadow
-  TcIn in;
-  tc_issue_loads<FUSED>(in, a, fz, a.env_begin + blockIdx.x * epb, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
-
-  // ---- replica-independent tables: agent types, ascending tagger list, action tables
-  const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
-  if (tab_in_lds) {
-    for (int i = tid; i < n_acc; i += T_) l.acc_tab[i] = a.acc_actions[i];
-    for (int i = tid; i < n_turn; i += T_) l.turn_tab[i] = a.turn_actions[i];
-  }
-  int n_taggers = 0;
-  {
-    // rank of a tagger = number of taggers with a smaller id: wave ballots + per-wave counts
-    const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
-    if (N <= T_) {  // usual case: one barrier
-      const int ty = (tid < N) ? a.agent_types[tid] : 0;
-      if (tid < N) l.types[tid] = ty;
-      const unsigned long long m = __ballot(ty == 1);
-      if (lane == 0) l.wave_cnt[wave] = __popcll(m);
-      __syncthreads();
-      int before = 0;
-      for (int w2 = 0; w2 < n_waves; ++w2) {
-        const int c = l.wave_cnt[w2];
-        before += (w2 < wave) ? c : 0;
-        n_taggers += c;
-      }
-      if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = tid;
-    } else {
-      for (int base = 0; base < N; base += T_) {
-        const int i = base + tid;
-        const int ty = (i < N) ? a.agent_types[i] : 0;
-        if (i < N) l.types[i] = ty;
-        const unsigned long long m = __ballot(ty == 1);
-        if (lane == 0) l.wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int before = n_taggers;
-        for (int w2 = 0; w2 < wave; ++w2) before += l.wave_cnt[w2];
-        if (ty == 1) l.tagger_ids[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        for (int w2 = 0; w2 < n_waves; ++w2) n_taggers += l.wave_cnt[w2];
-        __syncthreads();
-      }
-    }
-  }
-  // (tagger_ids / action tables are first read after the barriers inside the replica loop)
-
-  // rotated loop: the loads of trip i+1 are issued at the end of trip i, so `in` is live only
-  // from issue to use (never across the body)
   int env0 = a.env_begin + blockIdx.x * epb;
-  if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
+  TcIn in;
+  tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
+  const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
+  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds);
+  if (env0 >= a.E) return;
+
   while (true) {
     const int env = env0 + el;
     const bool active = (el < epb) && (env < a.E);
-    const int gi = env * N + ag;  // index into [E, N] arrays
-    const int li = el * N + ag;   // index into LDS arrays
+    const int gi = env * N + ag;
+    const int li = el * N + ag;
+    int2 sampled = in.sampled;
+    if (FUSED) {
+      if (active && ag == 0) a.done[env] = 0;
+      sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ move
     float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
     const int sg = in.sg;
-    const float dir_in = in.dir, acc_in = in.acc, speed_in = in.speed, x_in = in.x, y_in = in.y, skill = in.skill;
-    int2 sampled = in.sampled;
-    WD_TC_STAMP(1);
-
-    // ------------------------------------------- fused tick: sample both action heads
-    // (replaces two sample_actions launches, random.cu:51-85): inverse CDF on a running
-    // float32 sum, one Philox call for both heads.
-    if (FUSED) {
-      if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
-      wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
-      if (active) {
-        fz.rng_state[WD_RNG_HEADER + gi] = in.epoch + 1u;
-        rnd = wd_philox4x32_10(wd_u4{(uint32_t)gi, in.epoch, (uint32_t)fz.stream_tag, 3u}, fz.rng_state[0],
-                               fz.rng_state[1]);
-      }
-      // every global_load_lds of this wavefront has landed once its vmcnt drains; the rows a lane
-      // reads were all fetched by its own wavefront
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      if (active) {
-        sampled.x = tc_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
-        sampled.y = tc_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
-      }
-      if (active) ((int2 *)fz.actions_out)[gi] = sampled;
-    }
-    __syncthreads();  // prologue tables (first iteration) / previous iteration's LDS readers
-
-    WD_TC_STAMP(2);
-    // ------------------------------------------------------------ phase 0: move
+    const bool is_runner = active && (in.type == 0) && (sg != 0);
     if (active) {
-      const float s = (float)sg;
-      const int2 act = sampled;
-      // (value select, not pointer select: a pointer that may be LDS or global becomes a flat access)
-      float d_acc = l.acc_tab[min(act.x, WD_TC_TAB - 1)], d_turn = l.turn_tab[min(act.y, WD_TC_TAB - 1)];
-      asm volatile("" : "+v"(d_acc), "+v"(d_turn));  // keeps the two loads from being merged into one flat load
-      if (!tab_in_lds) {
-        d_acc = a.acc_actions[act.x];
-        d_turn = a.turn_actions[act.y];
-      }
-      const float dir = wd_np_remainderf(dir_in + d_turn, two_pi) * s;            // :355-357
-      float acc = acc_in + d_acc;                                                 // :359
-      const float vmax = a.max_speed * skill;                                     // :363
-      float v = speed_in + acc;
-      v = fminf(fmaxf(v, 0.0f), vmax) * s;                                        // :364-366
-      acc = acc * (v > 0.0f ? 1.0f : 0.0f) * (v < vmax ? 1.0f : 0.0f);            // :367
-      float sn, cs;
-      wd_np_sincosf(dir, sn, cs);
-      float px = x_in + v * cs;                                                   // :369-374
-      float py = y_in + v * sn;
-      const bool crossed = !((px >= 0.0f) && (px <= L) && (py >= 0.0f) && (py <= L));
-      px = fminf(fmaxf(px, 0.0f), L);                                             // :385-391
-      py = fminf(fmaxf(py, 0.0f), L);
-      edge_pen = a.edge_hit_penalty * (crossed ? 1.0f : 0.0f);                    // :394
-      a.loc_x[gi] = px;
-      a.loc_y[gi] = py;
-      a.speed[gi] = v;
-      a.direction[gi] = dir;
-      a.acceleration[gi] = acc;
-      a.edge_pen_arr[gi] = edge_pen;
-      my_x = px;
-      my_y = py;
-      // agents out of the game are pushed to +BIG for the neighbour search only; every other
-      // consumer (taggers are never out of the game) reads real positions
-      l.xy[li] = make_float2(sg ? px : WD_BIG, py);
-      TcFeat ft;
-      ft.nx = (double)px / diag;    // :462 (float64 division)
-      ft.ny = (double)py / diag;
-      ft.nsp = v / sp_div;          // float32 division (:456-458)
-      ft.nac = acc / sp_div;
-      ft.ndir = dir / two_pi;
-      ft.type_sig = (l.types[ag] & 1) | (sg ? 2 : 0);
-      ft.pad_[0] = 0; ft.pad_[1] = 0;
-      l.feat[li] = ft;
+      const TcMoved m = tc_move(a, tb, in, sampled, gi, tab_in_lds);
+      edge_pen = m.edge_pen; my_x = m.x; my_y = m.y;
+      l.xy[li] = make_float2(m.x, m.y);
+      l.feat[li] = m.ft;
       l.sig[li] = sg;
       l.tagcnt[li] = 0;
       if (ag == 0) {
-        const int t = a.timestep[env] + 1;  // :800
+        const int t = a.timestep[env] + 1;
         a.timestep[env] = t;
-        l.tstep[el] = t;
-        l.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474
-        l.nrun[el] = a.num_runners[env];
+        tb.tstep[el] = t;
+        tb.tfrac[el] = (float)((double)t / (double)a.T);
+        tb.nrun[el] = a.num_runners[env];
       }
     }
     __syncthreads();
 
-    WD_TC_STAMP(3);
-    // ------------------------------------------------ phase 1: K nearest neighbours
-    if (!a.use_full_obs && active && !(WD_TC_ABLATE & 1)) {
-      if (l.sig[li]) {
-        if (KMAX > 0) tc_knn_registers<(KMAX > 0 ? KMAX : 1)>(l, el, ag, li, N, K);
-        else tc_knn_generic(l, el, ag, li, N, K);
-      } else {
-        int *out = (int *)(l.cand + (size_t)li * (K + 1));
-        for (int k = 0; k < K; ++k) out[k] = -1;
-      }
+    // ------------------------------------------------------------ tags + K nearest neighbours
+    bool tagged = false;
+    if (is_runner)
+      tagged = tc_find_tag(a, tb, l.xy + el * N, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
+    if (!a.use_full_obs && active) {
+      int *out = l.nbr + (size_t)li * K;
+      if (sg) tc_knn_generic(l.xy + el * N, l.sig + el * N, out, ag, N, K);
+      else for (int k = 0; k < K; ++k) out[k] = -1;
     }
     __syncthreads();
 
-    WD_TC_STAMP(7);
-    // ------------------------------------------------ phase 2: observations
-    // One work item = (agent row m, neighbour slot k): it reads the neighbour id once, then
-    // the 7 features of that neighbour and of the agent, and writes the 7 columns
-    // {c*W + k} of the row.  Consecutive lanes hold consecutive k, so every store
-    // instruction writes runs of W consecutive floats (whole 256-byte lines in the
-    // full-observation mode); only two dependent LDS round trips per 7 outputs.
-    if (!(WD_TC_ABLATE & 2)) {
+    // ------------------------------------------------------------ observations
+    // One work item = (agent row m, neighbour slot k): it reads the neighbour id once, then the 7
+    // features of that neighbour and of the agent, and writes the 7 columns {c*W + k} of the row.
+    {
       const int agents_here = min(epb, a.E - env0) * N;
       const int items = agents_here * W;
       float *obs_blk = a.obs + (long)env0 * N * F;
       const int Wd = max(W, 1);
-      int k = tid % Wd, m = tid / Wd;         // block-local agent row and slot of the first item
-      int i = m % N;                          // agent id inside its replica
-      const int sk = T_ % Wd, sm = T_ / Wd, si = sm % N;
-      if (KMAX == 0 && a.use_full_obs && (W & 3) == 0 && W > 0 && !(WD_TC_ABLATE & (16 | 64 | 128))) {
-        // (generic entry points only: the host launches full observations through them, and the
-        // K-specialised kernels have no registers to spare)
+      if (a.use_full_obs && (W & 3) == 0 && W > 0) {
         // Full observations: rows are 7 runs of W consecutive floats, and the phase is bound by the
         // number of store instructions (612 MB per tick at N = 105).  One work item = (row, four
-        // consecutive slots): 28 values, seven 16-byte stores (dword-aligned addresses) -- 4x fewer
-        // store instructions than one float per lane.
+        // consecutive slots): 28 values, seven 16-byte stores (dword-aligned addresses).
         const int nq = W >> 2;
         int q = tid % nq, mq = tid / nq, iq = mq % N;
         const int sq = T_ % nq, smq = T_ / nq, siq = smq % N;
@@ -807,13 +977,10 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
           for (int kk = 0; kk < 4; ++kk) {
             const int kcol = 4 * q + kk;
             const TcFeat nb = l.feat[ebase + kcol + (kcol >= iq ? 1 : 0)];
-            v[0][kk] = in_game ? (float)(nb.nx - me.nx) : 0.0f;
-            v[1][kk] = in_game ? (float)(nb.ny - me.ny) : 0.0f;
-            v[2][kk] = in_game ? (nb.nsp - me.nsp) : 0.0f;
-            v[3][kk] = in_game ? (nb.nac - me.nac) : 0.0f;
-            v[4][kk] = in_game ? (nb.ndir - me.ndir) : 0.0f;
-            v[5][kk] = (float)(nb.type_sig & 1);
-            v[6][kk] = (float)((nb.type_sig >> 1) & 1);
+            float vals[7];
+            tc_obs_values(vals, nb, me, in_game, true);  // type / still_in_game columns are always filled
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v[c][kk] = vals[c];
           }
           float *row = obs_blk + (long)mq * F + 4 * q;
 #pragma unroll
@@ -825,146 +992,53 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
           iq += siq + carry;
           iq -= (iq >= N) ? N : 0;
         }
-      } else
-      for (int t = tid; t < items; t += T_) {
-        const int ebase = m - i;              // first agent of this row's replica
-        const bool in_game = l.sig[m] != 0;
-        int j;
-        bool valid;
-        if (a.use_full_obs) {
-          j = k + (k >= i ? 1 : 0);
-          valid = true;   // type / still_in_game columns are filled even for agents out of the game
-        } else {
-          j = ((const int *)l.cand)[(size_t)m * row_ints + k];
-          valid = in_game && (j >= 0);
-          j = max(j, 0);
-        }
-        const int o = ebase + j;
-        float *row = obs_blk + (long)m * F;
-        const bool rel = valid && in_game;  // relative features only for agents in the game
-        TcFeat nb, me;
-        if (WD_TC_ABLATE & 64) {  // timing experiment: no LDS feature reads
-          nb.nx = 1.0 + o; nb.ny = 2.0; nb.nsp = 0.5f; nb.nac = 0.25f; nb.ndir = 0.125f; nb.type_sig = o;
-          me = nb; me.nx = 0.5;
-        } else {
-          nb = l.feat[o];
-          me = l.feat[m];
-        }
-        float vals[7];
-        // float64 differences (:560), narrowed to float32 like the reference's device push
-        vals[0] = rel ? (float)(nb.nx - me.nx) : 0.0f;
-        vals[1] = rel ? (float)(nb.ny - me.ny) : 0.0f;
-        // speed / acc / dir: the reference widens float32 values and subtracts in float64; for
-        // float32 operands that rounds to exactly the float32 difference (53 >= 2*24+2 bits:
-        // double rounding is innocuous), so no float64 arithmetic is needed here
-        vals[2] = rel ? (nb.nsp - me.nsp) : 0.0f;
-        vals[3] = rel ? (nb.nac - me.nac) : 0.0f;
-        vals[4] = rel ? (nb.ndir - me.ndir) : 0.0f;
-        vals[5] = valid ? (float)(nb.type_sig & 1) : 0.0f;
-        vals[6] = valid ? (float)((nb.type_sig >> 1) & 1) : 0.0f;
-        if (WD_TC_ABLATE & 16) {  // timing experiment: keep the math, drop the stores
-          float acc = 0.f;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) acc += vals[c];
-          if (acc == 123.456f) row[0] = acc;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 7; ++c) {
-            if (WD_TC_ABLATE & 128)  // timing experiment: same bytes, fully coalesced (wrong layout)
-              tc_store_obs(obs_blk + (long)c * items + t, vals[c]);
-            else
-              tc_store_obs(row + c * W + k, vals[c]);
+      } else {
+        int k = tid % Wd, m = tid / Wd;         // block-local agent row and slot of the first item
+        int i = m % N;                          // agent id inside its replica
+        const int sk = T_ % Wd, sm = T_ / Wd, si = sm % N;
+        for (int t = tid; t < items; t += T_) {
+          const int ebase = m - i;              // first agent of this row's replica
+          const bool in_game = l.sig[m] != 0;
+          int j;
+          bool valid;
+          if (a.use_full_obs) {
+            j = k + (k >= i ? 1 : 0);
+            valid = true;
+          } else {
+            j = l.nbr[(size_t)m * K + k];
+            valid = in_game && (j >= 0);
+            j = max(j, 0);
           }
+          const TcFeat nb = l.feat[ebase + j], me = l.feat[m];
+          float vals[7];
+          tc_obs_values(vals, nb, me, valid && in_game, valid);
+          float *row = obs_blk + (long)m * F;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) row[c * W + k] = vals[c];
+          k += sk;
+          const int carry = (k >= W) ? 1 : 0;
+          k -= carry ? W : 0;
+          m += sm + carry;
+          i += si + carry;
+          i -= (i >= N) ? N : 0;
         }
-        // advance (m, i, k) by the block stride
-        k += sk;
-        int carry = (k >= W) ? 1 : 0;
-        k -= carry ? W : 0;
-        m += sm + carry;
-        i += si + carry;
-        i -= (i >= N) ? N : 0;
       }
       // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
-      if (!(WD_TC_ABLATE & 32))
       for (int m0 = tid; m0 < agents_here; m0 += T_)
-        tc_store_obs(obs_blk + (long)m0 * F + 7 * W, (l.sig[m0] != 0) ? l.tfrac[m0 / N] : 0.0f);
-      if (!a.use_full_obs && K > 0 && !(WD_TC_ABLATE & 32)) {
+        obs_blk[(long)m0 * F + 7 * W] = (l.sig[m0] != 0) ? tb.tfrac[m0 / N] : 0.0f;
+      if (!a.use_full_obs && K > 0) {
         int *nb_blk = a.nearest_ids + (long)env0 * N * K;
-        int k2 = tid % K, m2 = tid / K;
-        const int sk2 = T_ % K, sm2 = T_ / K;
-        for (int q = tid; q < agents_here * K; q += T_) {
-          nb_blk[q] = ((const int *)l.cand)[(size_t)m2 * row_ints + k2];
-          k2 += sk2;
-          const int carry = (k2 >= K) ? 1 : 0;
-          k2 -= carry ? K : 0;
-          m2 += sm2 + carry;
-        }
+        for (int q = tid; q < agents_here * K; q += T_) nb_blk[q] = l.nbr[q];
       }
     }
 
-    WD_TC_STAMP(9);
-    // ------------------------------------------------------------ phase 3: rewards
-    float rew = 0.0f;
-    bool tagged = false, is_runner = false;
-    if (active) {
-      const int sg = l.sig[li];
-      if (sg) { rew += edge_pen; rew += a.step_rewards[ag]; }  // :655-658
-      is_runner = (l.types[ag] == 0) && (sg != 0);              // member of self.runners
-      if (is_runner) {
-        float best = __builtin_inff();
-        int bt = -1;
-        for (int t = 0; t < n_taggers; ++t) {  // ascending ids, first minimum wins :643-651
-          const int j = l.tagger_ids[t];
-          const float2 pt = l.xy[el * N + j];
-          const float dx = my_x - pt.x, dy = my_y - pt.y;
-          const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
-          if (d < best) { best = d; bt = j; }
-        }
-        if (bt >= 0 && best < a.margin) {  // :661
-          tagged = true;
-          atomicAdd(&l.tagcnt[el * N + bt], 1);
-          if (a.runner_exits) atomicSub(&l.nrun[el], 1);
-        }
-      }
-    }
-    __syncthreads();
-    if (active) {
-      if (tagged) rew += a.tag_penalty;                             // :664
-      const int c = l.tagcnt[li];
-      for (int k = 0; k < c; ++k) rew += a.tag_reward;              // :665, one add per tag
-      const bool still_runner = is_runner && !(tagged && a.runner_exits);
-      if (l.tstep[el] == a.T && still_runner) rew += a.end_reward;  // :674-676
-      a.rewards[gi] = rew;
-      if (tagged && a.runner_exits) a.sig_arr[gi] = 0;              // :669
-      if (ag == 0) {
-        const int nr = l.nrun[el];
-        a.num_runners[env] = nr;
-        const bool fin = (l.tstep[el] >= a.T || nr == 0);           // :880-883
-        if (fin) a.done[env] = 1;
-        if (FUSED) l.doneflag[el] = fin ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    WD_TC_STAMP(10);
-    // ------------------------------------------- fused tick: reset finished replicas in place
-    // (reset.cu:9-75 for every registered array).  `_done_` stays 1 so the trainer can read
-    // which replicas finished on this tick; the next tick clears it.  All writes of this block
-    // to these rows happened before the barrier above.
-    if (FUSED) {
-      const int envs_here = min(epb, a.E - env0);
-      for (int e = 0; e < envs_here; ++e) {
-        if (l.doneflag[e] == 0) continue;  // block-uniform
-        for (int r = 0; r < fz.n_reset_arrays; ++r) {
-          const TcResetEntry ent = fz.reset_table[r];
-          const long base = (long)(env0 + e) * ent.row_elems;
-          for (int i = tid; i < ent.row_elems; i += T_) ent.data[base + i] = ent.ref[base + i];
-        }
-        if (tid == 0) a.timestep[env0 + e] = 0;
-      }
-      __syncthreads();
-    }
+    // ------------------------------------------------------------ rewards / done
+    if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, FUSED);
+    __syncthreads();  // (also: all stores of the tick to this replica's rows are issued)
+    if (FUSED) tc_reset_finished(a, fz, tb, env0, epb);
     env0 += gridDim.x * epb;
     if (env0 >= a.E) break;
+    __syncthreads();
     tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
   }
 }
@@ -1000,16 +1074,7 @@ __device__ __forceinline__ void tc_step_impl(const TcArgs &a, const TcFuse &fz, 
   a.tag_penalty = kTagPenaltyForRunner; a.end_reward = kEndOfGameRewardForRunner;                 \
   a.done = done_arr; a.timestep = env_timestep_arr; a.N = kNumAgents; a.T = kEpisodeLength;       \
   a.E = kNumEnvs; a.env_begin = kEnvBegin;                                                        \
-  a.prof = (unsigned long long *)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
-
-extern "C" {
-
-// generic entry: any K (and the full-observation mode)
-__global__ void HipTagContinuousStep(WD_TC_PARAMS) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
-  WD_TC_PACK();
-  tc_step_impl<0, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);
-}
+  (void)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
 
 // Fused rollout tick: sample both action heads + step + reset finished replicas in ONE launch
 // (the reference needs 2 sampler launches, the step, and 13 reset launches per tick,
@@ -1024,26 +1089,34 @@ __global__ void HipTagContinuousStep(WD_TC_PARAMS) {
   fz.reset_table = (const TcResetEntry *)reset_table; fz.n_reset_arrays = n_reset_arrays;      \
   fz.stream_tag = stream_tag;
 
+extern "C" {
+
+// generic entries: any N <= 1024, any K, and the full-observation mode
+__global__ void HipTagContinuousStep(WD_TC_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  WD_TC_PACK();
+  tc_generic_impl<false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);
+}
+
 __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
   WD_TC_PACK();
   WD_TC_FUSE_PACK();
-  tc_step_impl<0, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
+  tc_generic_impl<true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
-// register-resident top-K specialisations (blocks of <= 512 threads); the host picks the
-// smallest KMAX >= K and falls back to the generic entry for > 512 agents per replica
+// fast entries (N <= 128, partial observations, K <= KM); the host picks the smallest KM >= K
 #define WD_TC_SPECIALISE(KM, WAVES)                                                                 \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
-    tc_step_impl<KM, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
+    tc_fast_impl<KM, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
   }                                                                                            \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     WD_TC_FUSE_PACK();                                                                         \
-    tc_step_impl<KM, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);          \
+    tc_fast_impl<KM, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);          \
   }
 WD_TC_SPECIALISE(2, 4)
 WD_TC_SPECIALISE(4, 4)

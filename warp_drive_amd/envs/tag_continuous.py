@@ -267,9 +267,7 @@ class TagContinuous(CUDAEnvironmentContext):
         # The reference registers two [N, N-1] scratch arrays the CUDA kernel sorts in HBM
         # (and resets: 2 x 43.7 KB per replica at N = 105).  The HIP kernel selects neighbours
         # in registers, so they shrink to one-element placeholders that keep the names valid.
-        # (WD_TC_PROFILE builds reuse this pointer for phase time stamps: 16 x uint64 per block)
-        n_prof = 32 * 4096 if os.environ.get("WD_TC_PROFILE") else 1
-        feed.add_data(name="neighbor_distances", data=np.zeros((n_prof,), dtype=np.float32))
+        feed.add_data(name="neighbor_distances", data=np.zeros((1,), dtype=np.float32))
         feed.add_data(name="neighbor_ids_sorted_by_distance", data=np.zeros((1,), dtype=np.int32))
         feed.add_data(name="nearest_neighbor_ids", data=np.zeros((n, K), dtype=np.int32),
                       save_copy_and_apply_at_reset=True)
@@ -288,40 +286,56 @@ class TagContinuous(CUDAEnvironmentContext):
         "num_acceleration_actions", "num_turn_actions",
     ]  # + kEnvBegin appended by step_launch / tick_launch
 
+    FAST_PATH_MAX_AGENTS = 128   # tc_fast_impl: neighbour masks of 4 x 32 bits
+    STAGE_TARGET_BYTES = 5400    # WD_TC_STAGE_TARGET in tag_continuous.hip
+
+    def _fast_path(self):
+        return (not self.use_full_observation and self.num_agents <= self.FAST_PATH_MAX_AGENTS
+                and 1 <= self.num_other_agents_observed <= _K_SPECIALISATIONS[-1])
+
     def resolve_step_function_name(self, default_name):
-        """Pick the register-resident top-K specialisation that covers K (partial obs only)."""
-        if self.use_full_observation or self.num_agents > 512:
+        """The register-resident top-K specialisation that covers K (N <= 128, partial obs), else the
+        generic kernel."""
+        if not self._fast_path():
             return default_name
         for k in _K_SPECIALISATIONS:
             if k >= self.num_other_agents_observed:
                 return f"{default_name}_K{k}"
         return default_name
 
-    def lds_bytes(self, epb, fused=False):
-        """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve in the kernel)"""
+    def lds_bytes(self, epb, fused=False, threads=None):
+        """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve_fast /
+        tc_carve_generic in the kernel file)"""
         N = self.num_agents
         A = epb * N
         K = 0 if self.use_full_observation else self.num_other_agents_observed
+
         def align16(v):
             return (v + 15) // 16 * 16
 
-        area = 48 * A + align16(8 * A * (K + 1)) + 4 * 4 * A   # features, lists, positions + 2 flag arrays
+        if self._fast_path():
+            F = 7 * K + 1
+            n_waves = ((A if threads is None else threads) + 63) // 64
+            stage_rows = max(1, min(64, self.STAGE_TARGET_BYTES // (4 * F)))
+            stage_dwords = align16(4 * stage_rows * F) // 4 + 4
+            area = 32 * A + 8 * A + 4 * A + 4 * A               # features, positions, 2 flag arrays
+            area = align16(area + 2 * A * K) + 4 * stage_dwords * n_waves  # 16-bit neighbour ids, staging
+        else:
+            area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
         if fused:  # the work area doubles as the two probability slabs (global_load_lds targets)
             area = max(area, align16(4 * A * len(self.acceleration_actions)) + align16(4 * A * len(self.turn_actions)))
         return align16(area) + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16
 
     def _geometry(self):
-        # 256 threads = one wavefront per SIMD: measured 1.3x faster than the denser 320-thread
-        # packing (3 replicas) whose 5 wavefronts load the 4 SIMDs unevenly
+        """(replicas per block, block, grid): whole replicas packed into blocks of at most 256 threads
+        with the fewest idle lanes -- 105 agents: one replica per 128-thread block (two wavefronts),
+        5 agents: 51 replicas per 256-thread block.  ONE trip per block: grid = ceil(replicas / epb)
+        (tc_fast_impl relies on it).  Full observations prefer the largest such block: that phase is
+        bound by the store path and 4-wave blocks keep twice the stores in flight
+        (scripts/write_pattern_probe.py)."""
         max_threads = int(os.environ.get("WD_TC_MAX_THREADS", "256"))  # override: geometry experiments
-        # full observations are bound by the store path: 4-wave blocks keep twice the stores in flight
-        # (scripts/write_pattern_probe.py: 2000 x 299 KB slices, 16-byte stores: 3.7 TB/s at 128 threads,
-        # 5.2 TB/s at 256); with K neighbours the two geometries measure the same
-        epb, block, grid = self.cuda_function_manager.packed_geometry(
+        return self.cuda_function_manager.packed_geometry(
             self.num_agents, max_threads=max_threads, prefer_large=bool(self.use_full_observation))
-        if "WD_TC_GRID" in os.environ:  # experiments: fewer blocks, each looping over replica groups
-            grid = (min(grid[0], int(os.environ["WD_TC_GRID"])), 1)
-        return epb, block, grid
 
     def _range_args(self, env_range):
         """step-kernel arguments for replicas [begin, end): kNumEnvs carries `end`, kEnvBegin `begin`"""
@@ -338,7 +352,7 @@ class TagContinuous(CUDAEnvironmentContext):
     def step_launch(self, env_range=None):
         """(function, args, block, grid, shared_bytes) of one device tick (optionally of a replica range)."""
         args, epb, block, grid = self._range_args(env_range)
-        return self.cuda_step, args, block, grid, self.lds_bytes(epb)
+        return self.cuda_step, args, block, grid, self.lds_bytes(epb, threads=block[0])
 
     LDS_PER_WORKGROUP = 160 * 1024  # gfx950
 
@@ -346,8 +360,8 @@ class TagContinuous(CUDAEnvironmentContext):
         """False when the fused tick's LDS image (work area or the two probability slabs, whichever is
         larger) does not fit a workgroup -- e.g. ~1000 agents with 21-way action heads; the rollout then
         uses the separate sampler / step / reset launches."""
-        epb, _, _ = self._geometry()
-        return self.lds_bytes(epb, fused=True) <= self.LDS_PER_WORKGROUP
+        epb, block, _ = self._geometry()
+        return self.lds_bytes(epb, fused=True, threads=block[0]) <= self.LDS_PER_WORKGROUP
 
     def tick_launch(self, sampler, probabilities, resetter, env_range=None):
         """Fused rollout tick: sample both action heads + step + reset finished replicas in ONE
@@ -365,7 +379,7 @@ class TagContinuous(CUDAEnvironmentContext):
         assert len(probabilities) == 2
         args, epb, block, grid = self._range_args(env_range)
         args = args + [sampler.rng_state, probabilities[0], probabilities[1], table, n_arrays, _stream_tag("tick")]
-        return fn, args, block, grid, self.lds_bytes(epb, fused=True)
+        return fn, args, block, grid, self.lds_bytes(epb, fused=True, threads=block[0])
 
     # ------------------------------------------------------------------------------ step
     def step(self, actions=None):
