@@ -1,0 +1,98 @@
+"""Variant sets for experiments/variants.py: name -> [(file, old, new), ...]"""
+TC = "tag_continuous.hip"
+
+_FLUSH_OLD = "  for (int q = lane; q < nvec; q += 64) dv[q] = sv[q];"
+
+
+def _flush(policy):
+    if policy == "nt":
+        body = ("{ typedef float v4f_ __attribute__((ext_vector_type(4))); "
+                "__builtin_nontemporal_store(((const v4f_ *)sv)[q], &((v4f_ *)dv)[q]); }")
+    else:
+        body = ('{ typedef float v4f_ __attribute__((ext_vector_type(4))); const v4f_ v_ = ((const v4f_ *)sv)[q]; '
+                'asm volatile("global_store_dwordx4 %0, %1, off ' + policy +
+                '" :: "v"(&dv[q]), "v"(v_) : "memory"); }')
+    return [(TC, _FLUSH_OLD, f"  for (int q = lane; q < nvec; q += 64) {body}")]
+
+
+SETS = {}
+SETS_RETIRED_store_policy = {
+    "store_policy": {
+        "base": [],
+        "nt": _flush("nt"),
+        "sc1": _flush("sc1"),
+        "sc0sc1": _flush("sc0 sc1"),
+        "sc1nt": _flush("sc1 nt"),
+    },
+}
+
+# ---- s_memtime stamps per wavefront at the phase boundaries of the fast path (experiments/phase_profile.py)
+_STAMP_DEFS = '''extern "C" { __device__ unsigned long long *tc_prof_g = nullptr; }
+#define TC_SLOT(k) ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k))
+#define TC_STAMP(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[TC_SLOT(k)] = __builtin_readcyclecounter(); } while (0)
+#define TC_STAMP_RT(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[TC_SLOT(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+namespace {
+'''
+PROFILE = [
+    (TC, "namespace {\n\nstruct TcArgs {", _STAMP_DEFS + "\nstruct TcArgs {"),
+    (TC, "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;\n  tc_issue_loads<FUSED>",
+     "  __builtin_amdgcn_s_setprio(3);\n  TC_STAMP_RT(14); TC_STAMP(0);\n  TcIn in;\n  tc_issue_loads<FUSED>"),
+    (TC, "  if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)\n\n  const int env = env0 + el;",
+     "  if (env0 >= a.E) return;\n  TC_STAMP(1);\n  const int env = env0 + el;"),
+    (TC, "  __syncthreads();  // tables are published; every wavefront is done with the slabs\n",
+     "  TC_STAMP(2);\n  __syncthreads();\n  TC_STAMP(3);\n"),
+    (TC, "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  __syncthreads();\n\n  // ------------------------------------------------------------ tags",
+     "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
+    (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX], rank[KMAX];",
+     "  TC_STAMP(6);\n  int nid[KMAX], rank[KMAX];"),
+    (TC, "  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest"),
+    (TC, "  // C. peel the (at most K) ids off the mask in ascending order", "  TC_STAMP(8);\n  // C. peel"),
+    (TC, "  // ------------------------------------------------------------ gather (wave-private from here",
+     "  TC_STAMP(9);\n  // ---- gather (wave-private from here"),
+    (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
+    (TC, "  __syncthreads();  // every runner's tag is counted\n", "  TC_STAMP(11);\n  __syncthreads();\n  TC_STAMP(12);\n"),
+    (TC, "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n}\n", "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n  TC_STAMP(13); TC_STAMP_RT(15);\n}\n"),
+]
+SETS["profile"] = {"prof": PROFILE}
+
+# ---- wave priority by phase: waves in EARLIER phases win VALU arbitration, so laggards catch up and
+# the wavefronts of a SIMD finish together (default arbitration is oldest-first: leaders stay leaders
+# and the last wave runs alone, latency-bound)
+def _prio(p_head, p_a, p_bc, p_gather):
+    return [
+        (TC, "  const int env0 = a.env_begin + blockIdx.x * epb;\n  TcIn in;",
+         f"  const int env0 = a.env_begin + blockIdx.x * epb;\n  __builtin_amdgcn_s_setprio({p_head});\n  TcIn in;"),
+        (TC, "  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * N, ag, N, K, nid);",
+         f"  __builtin_amdgcn_s_setprio({p_a});\n  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * N, ag, N, K, nid);\n"
+         f"  __builtin_amdgcn_s_setprio({p_gather});"),
+        (TC, "  // B[k], k = 1..K are the K smallest squared distances to OTHER agents",
+         f"  __builtin_amdgcn_s_setprio({p_bc});\n  // B[k], k = 1..K are the K smallest"),
+    ]
+
+
+def _cohort(us):
+    return [(TC, "  const int env0 = a.env_begin + blockIdx.x * epb;\n  TcIn in;",
+             "  const int env0 = a.env_begin + blockIdx.x * epb;\n"
+             "  if (blockIdx.x >= (gridDim.x >> 1)) {\n"
+             "    const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n"
+             f"    while (__builtin_amdgcn_s_memrealtime() - t0_ < {int(us * 100)}ull) __builtin_amdgcn_s_sleep(8);\n"
+             "  }\n  TcIn in;")]
+
+
+SETS_RETIRED_sched = {
+    "base": [],
+    "prio3210": _prio(3, 2, 1, 0),
+    "prio3310": _prio(3, 3, 1, 0),
+    "prio0123": _prio(0, 1, 2, 3),
+    "prio2210": _prio(2, 2, 1, 0),
+    "cohort3": _cohort(3),
+    "cohort6": _cohort(6),
+}
+
+
+SETS["flags"] = {
+    "base": [],
+    "noslp": [(None, "flag", "-fno-slp-vectorize")],
+    "O2": [(None, "flag", "-O2")],
+    "sched_ilp": [(None, "flag", "-mllvm"), (None, "flag", "-amdgpu-schedule-metric-bias=0")],
+}

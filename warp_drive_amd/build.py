@@ -29,6 +29,10 @@ KERNEL_FLAGS = [
     # the fused tick kernels restore registered arrays through the reset table's untyped 32-bit
     # pointers, which alias the typed kernel arguments: no type-based alias analysis
     "-fno-strict-aliasing",
+    # no SLP vectorisation: it pairs float32 add/mul into v_pk_add_f32 / v_pk_mul_f32, which issue at
+    # less than half the rate of the plain VOP2 forms on gfx950 (experiments/ubench: 2.9 vs 1.2 cycles
+    # per wave-instruction per SIMD); measured 43.2 -> 41.0 us per TagContinuous tick
+    "-fno-slp-vectorize",
 ]
 
 

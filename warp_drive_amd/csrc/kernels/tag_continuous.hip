@@ -27,8 +27,8 @@
 //       search   per agent, in registers: (A) the K+1 smallest squared distances with a
 //                v_med3_f32 chain; (B) one 128-bit mask "d^2 <= the K-th" built with
 //                v_cmp + v_addc (ties at the float32-sqrt cut resolved exactly as the stable
-//                heapq.nsmallest does); (C) the <= K set bits peeled in id order and sorted by
-//                (sqrt(d^2), id) with a Batcher network;
+//                heapq.nsmallest does); (C) the <= K set bits peeled in id order and ranked by
+//                (sqrt(d^2), id) with pairwise compare-and-count;
 //       gather   each WAVEFRONT turns the rows of its own 64 agents into observation rows inside a
 //                private LDS staging buffer, a chunk of rows at a time, and streams every chunk out
 //                as one contiguous run of 16-byte stores (the [E, N, F] layout makes a replica's
@@ -96,7 +96,7 @@ struct TcFuse {
 struct __attribute__((aligned(16))) TcFeat {
   double nx, ny;
   float nsp, nac, ndir;
-  int type_sig;  // bit 0: agent type (1 = tagger), bit 1: still_in_the_game before tagging
+  int type_sig;  // float bits of the agent type (1.0f = tagger, 0) | bit 0: still_in_the_game before tagging
 };
 
 struct TcCand {
@@ -335,7 +335,7 @@ __device__ __forceinline__ TcMoved tc_move(const TcArgs &a, const TcTables &tb, 
   m.ft.nsp = v / sp_div;          // float32 division (:456-458)
   m.ft.nac = acc / sp_div;
   m.ft.ndir = dir / two_pi;
-  m.ft.type_sig = (in.type & 1) | (in.sg ? 2 : 0);
+  m.ft.type_sig = ((in.type & 1) ? 0x3f800000 : 0) | (in.sg ? 1 : 0);
   return m;
 }
 
@@ -345,13 +345,18 @@ __device__ __forceinline__ TcMoved tc_move(const TcArgs &a, const TcTables &tb, 
 // to exactly the float32 difference (53 >= 2*24+2 bits: double rounding is innocuous).
 __device__ __forceinline__ void tc_obs_values(float (&vals)[7], const TcFeat &nb, const TcFeat &me, bool rel,
                                               bool valid) {
-  vals[0] = rel ? (float)(nb.nx - me.nx) : 0.0f;
-  vals[1] = rel ? (float)(nb.ny - me.ny) : 0.0f;
-  vals[2] = rel ? (nb.nsp - me.nsp) : 0.0f;
-  vals[3] = rel ? (nb.nac - me.nac) : 0.0f;
-  vals[4] = rel ? (nb.ndir - me.ndir) : 0.0f;
-  vals[5] = valid ? (float)(nb.type_sig & 1) : 0.0f;
-  vals[6] = valid ? (float)((nb.type_sig >> 1) & 1) : 0.0f;
+  // masked with AND (all-ones / zero) rather than selected: a run of v_cndmask on one condition is
+  // several times slower than a run of v_and on gfx950, and the masked value is +0.0 exactly
+  unsigned mr = rel ? 0xffffffffu : 0u, mv = valid ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(mr), "+v"(mv));  // (opaque: the compiler would turn the ANDs back into selects)
+  vals[0] = __uint_as_float(__float_as_uint((float)(nb.nx - me.nx)) & mr);
+  vals[1] = __uint_as_float(__float_as_uint((float)(nb.ny - me.ny)) & mr);
+  vals[2] = __uint_as_float(__float_as_uint(nb.nsp - me.nsp) & mr);
+  vals[3] = __uint_as_float(__float_as_uint(nb.nac - me.nac) & mr);
+  vals[4] = __uint_as_float(__float_as_uint(nb.ndir - me.ndir) & mr);
+  const unsigned one = 0x3f800000u, ts = (unsigned)nb.type_sig;
+  vals[5] = __uint_as_float(ts & one & mv);
+  vals[6] = __uint_as_float((0u - (ts & 1u)) & one & mv);
 }
 
 // ---- tags: a runner in the game finds its nearest tagger (ascending ids, first minimum wins,
@@ -360,12 +365,20 @@ __device__ __forceinline__ bool tc_find_tag(const TcArgs &a, const TcTables &tb,
                                             int *nrun_env, int n_taggers, float my_x, float my_y) {
   float best = __builtin_inff();
   int bt = -1;
-  for (int t = 0; t < n_taggers; ++t) {
-    const int j = tb.tagger_ids[t];
-    const float2 pt = cxy[j];  // taggers are never out of the game: real positions
-    const float dx = my_x - pt.x, dy = my_y - pt.y;
-    const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
-    if (d < best) { best = d; bt = j; }
+  constexpr int U = 8;  // taggers per batch: all id reads, then all position reads, in flight together
+  for (int t0 = 0; t0 < n_taggers; t0 += U) {
+    int j[U];
+    float2 pt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) j[u] = tb.tagger_ids[min(t0 + u, n_taggers - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pt[u] = cxy[j[u]];  // taggers are never out of the game: real positions
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float dx = my_x - pt[u].x, dy = my_y - pt[u].y;
+      const float d = sqrtf(dx * dx + dy * dy);  // array ** 2 == x*x, :630-641
+      if (t0 + u < n_taggers && d < best) { best = d; bt = j[u]; }
+    }
   }
   if (bt >= 0 && best < a.margin) {
     atomicAdd(&tagcnt_env[bt], 1);
@@ -419,59 +432,28 @@ __device__ __forceinline__ void tc_reset_finished(const TcArgs &a, const TcFuse 
 //                   fast path: N <= 128, partial observations, K <= KMAX
 // =====================================================================================
 
-// compare-exchange of (distance, id) keys, ascending.  distance >= 0, so its float bits order
-// like an unsigned integer and (bits << 32 | id) is one total 64-bit key.
-__device__ __forceinline__ void tc_cex(unsigned long long &a, unsigned long long &b) {
-  const bool swap = a > b;
-  const unsigned long long lo = swap ? b : a, hi = swap ? a : b;
-  a = lo;
-  b = hi;
-}
-
-// Batcher's merge-exchange sorting network (Knuth 5.2.2 Algorithm M) for n keys, built at
-// compile time and fully unrolled: 31 compare-exchanges for n = 10 (odd-even transposition
-// needs 45).
-template <int n>
-struct TcNet {
-  int a[n * 8 + 1] = {}, b[n * 8 + 1] = {};
-  int count = 0;
+struct TcP4 {
+  float2 p[4];
 };
-
-template <int n>
-constexpr TcNet<n> tc_make_net() {
-  TcNet<n> net;
-  int t = 0;
-  while ((1 << t) < n) ++t;
-  if (t == 0) return net;
-  for (int p = 1 << (t - 1); p > 0; p >>= 1) {
-    int q = 1 << (t - 1), r = 0, d = p;
-    for (;;) {
-      for (int i = 0; i + d < n; ++i)
-        if ((i & p) == r) { net.a[net.count] = i; net.b[net.count] = i + d; ++net.count; }
-      if (q == p) break;
-      d = q - p;
-      q >>= 1;
-      r = p;
-    }
-  }
-  return net;
+// positions of candidates j .. j+3 (j even; every replica's positions start 16-byte aligned): two
+// ds_read_b128 with a wave-uniform address -- half the LDS cycles of four 8-byte reads, and the LDS
+// pipe is what bounds pass B otherwise
+__device__ __forceinline__ TcP4 tc_load4(const float2 *cxy, int j) {
+  const float4 a = *(const float4 *)(cxy + j), b = *(const float4 *)(cxy + j + 2);
+  TcP4 r;
+  r.p[0] = make_float2(a.x, a.y); r.p[1] = make_float2(a.z, a.w);
+  r.p[2] = make_float2(b.x, b.y); r.p[3] = make_float2(b.z, b.w);
+  return r;
 }
 
-template <int n>
-__device__ __forceinline__ void tc_sort_network(unsigned long long (&key)[n]) {
-  constexpr TcNet<n> net = tc_make_net<n>();
-#pragma unroll
-  for (int c = 0; c < net.count; ++c) tc_cex(key[net.a[c]], key[net.b[c]]);
-}
-
-// K nearest neighbours of agent `ag` among the N <= 128 agents of its replica, entirely in
-// registers.  cxy = the replica's post-move positions in LDS (x = +BIG for agents out of the game).
-// Result: nid[k], k < K = neighbour ids in the reference's order (float32 distance, then id;
-// -1 = fewer than k+1 candidates in the game).
 template <int KMAX>
-__device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX]) {
+__device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX],
+                                                 int (&rank)[KMAX]) {
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   const float INF = __builtin_inff();
+  // candidates are streamed four at a time, the next four positions being read from LDS while the
+  // current four are processed (the search is latency-bound otherwise: one LDS round trip per group)
+  const int jclamp = max((N - 4) & ~1, 0);
 
   // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
   //    agents out of the game contribute +inf): B[k] = med3(B[k-1], B[k], d2), one op per slot,
@@ -479,14 +461,33 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
   float B[KMAX + 1];
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) B[k] = INF;
-  for (int j = 0; j < N; ++j) {
-    const float2 pj = cxy[j];  // wave-uniform address: broadcast
-    const float dx = xi - pj.x, dy = yi - pj.y;
-    const float d2 = dx * dx + dy * dy;
+#define WD_TC_INSERT(d2v)                                                                         \
+  do {                                                                                            \
+    _Pragma("unroll") for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], (d2v)); \
+    B[0] = fminf(B[0], (d2v));                                                                    \
+  } while (0)
+  {
+    const int ng = N >> 2;
+    TcP4 nxt = tc_load4(cxy, 0);
+    for (int g = 0; g < ng; ++g) {
+      const TcP4 cur = nxt;
+      nxt = tc_load4(cxy, min(4 * g + 4, jclamp));
 #pragma unroll
-    for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], d2);
-    B[0] = fminf(B[0], d2);
+      for (int u = 0; u < 4; ++u) {
+        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;
+        const float d2 = dx * dx + dy * dy;
+        WD_TC_INSERT(d2);
+      }
+    }
+    for (int j = 4 * ng; j < N; ++j) {
+      const float2 pj = cxy[j];
+      const float dx = xi - pj.x, dy = yi - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      WD_TC_INSERT(d2);
+    }
   }
+#undef WD_TC_INSERT
+  __builtin_amdgcn_s_setprio(1);
   // B[k], k = 1..K are the K smallest squared distances to OTHER agents (B[0] is self or a
   // co-located twin).  T2 = the K-th of them.
   float T2 = INF;
@@ -514,47 +515,58 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
     T2lo = tl;
   }
   // B. second pass: one 128-bit per-lane mask "inside or below the range".  Each candidate costs
-  //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no LDS
-  //    traffic beyond the broadcast read, no data-dependent addressing.  Candidate b of word w lands
-  //    on bit (nb-1-b): undone with one bit-reverse per word.
+  //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no
+  //    data-dependent addressing.  Candidate b of word w lands on bit (nb-1-b): undone with one
+  //    bit-reverse per word.
   unsigned sel[4] = {0u, 0u, 0u, 0u};
   int n_upto = 0;
-  // (loop-invariant across trips, but hoisting them costs long-lived registers the kernel does not
-  // have at 128 VGPRs: the empty asm statements pin their computation here)
-  int ag_here = ag, n_here = N;
-  asm volatile("" : "+v"(ag_here));
-  asm volatile("" : "+s"(n_here));
 #define WD_TC_PUSH(m, d2v, thr, op) \
   asm("v_cmp_" op "_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(thr) : "vcc")
+  {
+#define WD_TC_PUSH4(m, g)                                                       \
+  do {                                                                          \
+    float d_[4];                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                             \
+      const float dx = xi - (g).p[u].x, dy = yi - (g).p[u].y;                   \
+      d_[u] = dx * dx + dy * dy;                                                \
+    }                                                                           \
+    WD_TC_PUSH(m, d_[0], T2hi, "le"); WD_TC_PUSH(m, d_[1], T2hi, "le");         \
+    WD_TC_PUSH(m, d_[2], T2hi, "le"); WD_TC_PUSH(m, d_[3], T2hi, "le");         \
+  } while (0)
+    TcP4 ga = tc_load4(cxy, 0), gb;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int j0 = 32 * w;
-    if (j0 < n_here) {  // wave-uniform
-      const int nb = min(32, n_here - j0);
-      unsigned mu = 0u;
-      // unrolled by hand (loops holding inline asm are not unrolled by the compiler) so the four
-      // LDS reads of a group are in flight together
-      int b = 0;
-      for (; b + 4 <= nb; b += 4) {
-        const float2 p0 = cxy[j0 + b], p1 = cxy[j0 + b + 1], p2 = cxy[j0 + b + 2], p3 = cxy[j0 + b + 3];
-        const float ax = xi - p0.x, ay = yi - p0.y, bx = xi - p1.x, by = yi - p1.y;
-        const float cx = xi - p2.x, cy = yi - p2.y, ex = xi - p3.x, ey = yi - p3.y;
-        const float d0 = ax * ax + ay * ay, d1 = bx * bx + by * by, d2 = cx * cx + cy * cy, d3 = ex * ex + ey * ey;
-        WD_TC_PUSH(mu, d0, T2hi, "le");
-        WD_TC_PUSH(mu, d1, T2hi, "le");
-        WD_TC_PUSH(mu, d2, T2hi, "le");
-        WD_TC_PUSH(mu, d3, T2hi, "le");
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int nb = min(32, N - j0);
+        unsigned mu = 0u;
+        int b = 0;
+        // two groups of four per trip, ping-pong: the loads of one group are in flight while the
+        // other is processed, and no register is copied
+        for (; b + 8 <= nb; b += 8) {
+          gb = tc_load4(cxy, min(j0 + b + 4, jclamp));
+          WD_TC_PUSH4(mu, ga);
+          ga = tc_load4(cxy, min(j0 + b + 8, jclamp));
+          WD_TC_PUSH4(mu, gb);
+        }
+        if (b + 4 <= nb) {
+          gb = tc_load4(cxy, min(j0 + b + 4, jclamp));
+          WD_TC_PUSH4(mu, ga);
+          ga = gb;
+          b += 4;
+        }
+        for (; b < nb; ++b) {  // (only the last word can have a remainder)
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
+          const float d2 = dx * dx + dy * dy;
+          WD_TC_PUSH(mu, d2, T2hi, "le");
+        }
+        const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
+        sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
+        n_upto += __popc(sel[w]);
       }
-      for (; b < nb; ++b) {
-        const float2 pj = cxy[j0 + b];
-        const float dx = xi - pj.x, dy = yi - pj.y;
-        const float d2 = dx * dx + dy * dy;
-        WD_TC_PUSH(mu, d2, T2hi, "le");
-      }
-      const unsigned self_bit = ((ag_here >> 5) == w) ? (1u << (ag_here & 31)) : 0u;
-      sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
-      n_upto += __popc(sel[w]);
     }
+#undef WD_TC_PUSH4
   }
   // Usually exactly K others are inside or below the range and the mask is the answer.  More
   // than K means several candidates share the K-th float32 distance: the reference keeps the
@@ -566,8 +578,8 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int j0 = 32 * w;
-      if (j0 < n_here) {
-        const int nb = min(32, n_here - j0);
+      if (j0 < N) {
+        const int nb = min(32, N - j0);
         unsigned mb = 0u;
         for (int b = 0; b < nb; ++b) {
           const float2 pj = cxy[j0 + b];
@@ -594,29 +606,45 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
     }
   }
 #undef WD_TC_PUSH
-  // C. peel the (at most K) ids off the mask in ascending order, rebuild their distances
-  //    and form 64-bit keys (float bits of sqrt(d2) << 32 | id), then sort
-  unsigned long long key[KMAX];
+  // C. peel the (at most K) ids off the mask in ascending order; read their positions (all reads in
+  //    flight together), rebuild the distances and form 64-bit keys (float bits of sqrt(d2) << 32 |
+  //    id); sort
+  int jj[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const int which = sel[0] ? 0 : sel[1] ? 1 : sel[2] ? 2 : sel[3] ? 3 : 4;
     const unsigned cur = sel[0] ? sel[0] : sel[1] ? sel[1] : sel[2] ? sel[2] : sel[3];
-    const bool have = which < 4;
-    const int j = have ? which * 32 + (__ffs(cur) - 1) : ag;
+    jj[k] = (which < 4) ? which * 32 + (__ffs(cur) - 1) : -1;
     const unsigned cleared = cur & (cur - 1u);
     sel[0] = (which == 0) ? cleared : sel[0];
     sel[1] = (which == 1) ? cleared : sel[1];
     sel[2] = (which == 2) ? cleared : sel[2];
     sel[3] = (which == 3) ? cleared : sel[3];
-    const float2 pj = cxy[j];
-    const float dx = xi - pj.x, dy = yi - pj.y;
-    const unsigned long long sbits =
-        have ? (unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000ull;
-    key[k] = (sbits << 32) | (unsigned long long)(unsigned int)(have ? j : 0xffff);
   }
-  tc_sort_network<KMAX>(key);
+  float2 pp[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) nid[k] = (key[k] >> 32) == 0x7f800000ull ? -1 : (int)(unsigned int)key[k];
+  for (int k = 0; k < KMAX; ++k) pp[k] = cxy[jj[k] < 0 ? ag : jj[k]];
+  unsigned sb[KMAX];  // float bits of the float32 distance (>= 0: they order like unsigned integers)
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const float dx = xi - pp[k].x, dy = yi - pp[k].y;
+    sb[k] = (jj[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
+    nid[k] = jj[k];
+  }
+  // rank of entry k in the reference's order (distance, then id): the entries are in ascending id
+  // order already, so entry j > i goes first only when it is STRICTLY closer.  Counting (one compare
+  // and two carry adds per pair) instead of a compare-exchange network: a 64-bit compare-exchange is
+  // a compare plus four v_cndmask, the slowest instruction class on gfx950 when they come in runs.
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+    for (int j = i + 1; j < KMAX; ++j) {
+      const int c = (sb[j] < sb[i]) ? 1 : 0;
+      rank[i] += c;
+      rank[j] -= c;
+    }
 }
 
 // Stream `n` dwords from a wavefront's staging buffer to global memory as one contiguous run.
@@ -628,9 +656,27 @@ __device__ __forceinline__ void tc_flush_run(const float *stage, float *dst, int
   const int head = min(n, (4 - mis) & 3);
   const int nvec = (n - head) >> 2;
   const int tail0 = head + 4 * nvec;
-  const float4 *sv = (const float4 *)(stage + mis + head);
-  float4 *dv = (float4 *)(dst + head);
-  for (int q = lane; q < nvec; q += 64) dv[q] = sv[q];
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f *sv = (const v4f *)(stage + mis + head);
+  v4f *dv = (v4f *)(dst + head);
+  // write-through (sc1) 16-byte stores: the rows go to memory as they are produced instead of piling
+  // up dirty in the L2 until the kernel-boundary write-back (47.0 -> 45.3 us per tick; 16-byte sc1
+  // stores cost the same as plain ones, narrower ones do not).  Three vectors per lane per trip, LDS
+  // reads in flight together; whole 64-lane groups are stored under wave-uniform branches, only the
+  // last partial group is exec-masked.
+#define WD_TC_STORE_WT(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(val) : "memory")
+  for (int base = 0; base < nvec; base += 192) {
+    const int nrem = nvec - base;  // wave-uniform
+    const int q = base + lane;
+    const v4f v0 = sv[min(q, nvec - 1)], v1 = sv[min(q + 64, nvec - 1)], v2 = sv[min(q + 128, nvec - 1)];
+    if (nrem >= 64) WD_TC_STORE_WT(&dv[q], v0);
+    else if (lane < nrem) WD_TC_STORE_WT(&dv[q], v0);
+    if (nrem >= 128) WD_TC_STORE_WT(&dv[q + 64], v1);
+    else if (lane + 64 < nrem) WD_TC_STORE_WT(&dv[q + 64], v1);
+    if (nrem >= 192) WD_TC_STORE_WT(&dv[q + 128], v2);
+    else if (lane + 128 < nrem) WD_TC_STORE_WT(&dv[q + 128], v2);
+  }
+#undef WD_TC_STORE_WT
   if (lane < head) dst[lane] = stage[mis + lane];
   if (lane < n - tail0) dst[tail0 + lane] = stage[mis + tail0 + lane];
 }
@@ -646,7 +692,7 @@ __device__ __forceinline__ int tc_stage_rows(int row_dwords) {
 // which are dead before the move phase writes it.
 struct TcFastLds {
   TcFeat *feat;          // [A] observation features
-  float2 *xy;            // [A] positions after the move (x = +BIG for agents out of the game)
+  float2 *xy;            // [epb][NP] positions after the move (x = +BIG for agents out of the game), NP = N rounded up to even
   int *sig;              // [A] still_in_the_game before this tick's tagging
   int *tagcnt;           // [A] tags credited to a tagger this tick
   unsigned short *ids;   // [A][K] block-local neighbour indices (0xffff = none)
@@ -662,7 +708,7 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   const int F = 7 * K + 1;
   size_t off = 0;
   l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
-  l.xy = (float2 *)(p0 + off); off += 8 * A;
+  l.xy = (float2 *)(p0 + off); off += 8 * (size_t)epb * ((N + 1) & ~1);  // even stride per replica
   l.sig = (int *)(p0 + off); off += 4 * A;
   l.tagcnt = (int *)(p0 + off); off += 4 * A;
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
@@ -689,12 +735,19 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   float *const stage = l.stage + (size_t)wave * l.stage_dwords;
   const int el = tid / N, ag = tid - el * N;
   const float invK = 1.0f / (float)K, invN = 1.0f / (float)N;
+  const int NP = (N + 1) & ~1;  // stride of a replica's positions in LDS (16-byte aligned pairs)
 
   // ONE trip per block (the host launches ceil(replicas / epb) blocks): every pointer argument is
   // used once and dies, which is what keeps the kernel inside 128 VGPRs / 104 SGPRs.
   // All global loads go out before anything else: the table set-up below (a dependent global load +
   // barrier) then runs in their shadow.
   const int env0 = a.env_begin + blockIdx.x * epb;
+  // Wave priority falls with the phase (3: fetch .. tags, 2: search A, 1: search B/C, 0: gather ..
+  // end): a wavefront that is behind wins VALU arbitration over one that is ahead, so the
+  // wavefronts of a SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
+  // and leaves the last wavefront of every SIMD running alone, latency-bound (measured: 48.6 ->
+  // 44.4 us per tick).
+  __builtin_amdgcn_s_setprio(3);
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
@@ -722,7 +775,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     edge_pen = m.edge_pen; my_x = m.x; my_y = m.y;
     // agents out of the game are pushed to +BIG for the neighbour search only; every other
     // consumer (taggers are never out of the game) reads real positions
-    l.xy[li] = make_float2(sg ? m.x : WD_BIG, m.y);
+    l.xy[el * NP + ag] = make_float2(sg ? m.x : WD_BIG, m.y);
     l.feat[li] = m.ft;
     l.sig[li] = sg;
     l.tagcnt[li] = 0;
@@ -740,13 +793,15 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // barrier that follows the gather)
   bool tagged = false;
   if (is_runner)
-    tagged = tc_find_tag(a, tb, l.xy + el * N, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
+    tagged = tc_find_tag(a, tb, l.xy + el * NP, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
 
   // ------------------------------------------------------------ search
-  int nid[KMAX];
+  int nid[KMAX], rank[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) nid[k] = -1;
-  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * N, ag, N, K, nid);
+  for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }
+  __builtin_amdgcn_s_setprio(2);
+  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid, rank);
+  __builtin_amdgcn_s_setprio(0);
 
   // ------------------------------------------------------------ gather (wave-private from here
   // to the barrier: rows [64*wave, 64*wave + wrows) of the block belong to this wavefront's lanes)
@@ -761,8 +816,8 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     if (active) {
       const int ebase = el * N;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
-        if (k < K) l.ids[(size_t)li * K + k] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
+      for (int k = 0; k < KMAX; ++k)  // (an entry's rank is < K unless it is one of the unused KMAX - K)
+        if (rank[k] < K) l.ids[(size_t)li * K + rank[k]] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
     }
     for (int r0 = 0; r0 < wrows; r0 += rows_per_pass) {
       const int rc = min(rows_per_pass, wrows - r0);
@@ -770,7 +825,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       if (lane >= r0 && lane < r0 + rc) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-          if (k < K) istage[mis + (lane - r0) * K + k] = nid[k];
+          if (rank[k] < K) istage[mis + (lane - r0) * K + rank[k]] = nid[k];
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -781,28 +836,64 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   }
   {
     // observation rows, R rows per chunk: work item = (row, neighbour slot) -> 7 values at
-    // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run
+    // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run.
+    // A chunk holds at most 192 items (tc_stage_rows), i.e. at most 3 per lane; their (row, slot)
+    // split is the same for every chunk and is worked out once.
     const int R = tc_stage_rows(F);
+    constexpr int U = 3;
+    int rr[U], so[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = lane + 64 * u;
+      rr[u] = (int)(((float)t + 0.5f) * invK);  // t / K (exact: the quotient is >= 0.5/K away from an integer)
+      so[u] = rr[u] * F + (t - rr[u] * K);      // offset of the item's first value in the chunk image
+    }
     float *const obs_w = a.obs + ((long)env0 * N + wrow0) * F;
     for (int r0 = 0; r0 < wrows; r0 += R) {
       const int rc = min(R, wrows - r0);
       float *const dst = obs_w + (long)r0 * F;
       const int mis = (int)(((size_t)dst >> 2) & 3);
       const int items = rc * K;
-      for (int t = lane; t < items; t += 64) {
-        const int r = (int)(((float)t + 0.5f) * invK);  // t / K (exact: the quotient is >= 0.5/K away from an integer)
-        const int k = t - r * K;
-        const int m = wrow0 + r0 + r;                   // block-local row
-        const unsigned j = l.ids[(size_t)m * K + k];
-        const TcFeat me = l.feat[m];
-        const bool in_game = (me.type_sig & 2) != 0;
-        const bool valid = in_game && (j != 0xffffu);
-        const TcFeat nb = l.feat[valid ? j : (unsigned)m];
-        float vals[7];
-        tc_obs_values(vals, nb, me, valid, valid);
-        float *o = stage + mis + r * F + k;
+      const unsigned short *const idp = l.ids + (size_t)(wrow0 + r0) * K;  // ids of item t: idp[t]
+      const TcFeat *const fp = l.feat + wrow0 + r0;
+      // ids, then feature records, all reads of a lane's items in flight together.  A lane whose item
+      // index is past the end recomputes the LAST item and writes the same values to the same place:
+      // straight-line code (exec-mask branches would cost more than the duplicate work)
+      int tt[U];
+      unsigned jq[U];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) o[c * K] = vals[c];
+      for (int u = 0; u < U; ++u) { tt[u] = min(lane + 64 * u, items - 1); jq[u] = idp[tt[u]]; }
+      const bool clamped2 = lane + 128 >= items, clamped1 = lane + 64 >= items, clamped0 = lane >= items;
+      TcFeat me[U], nb[U];
+      int off[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool cl = (u == 0) ? clamped0 : (u == 1) ? clamped1 : clamped2;
+        // (row, offset) of the item: precomputed for unclamped lanes, recomputed for the last item
+        const int r_last = rc - 1, o_last = r_last * F + (K - 1);
+        const int r = cl ? r_last : rr[u];
+        off[u] = cl ? o_last : so[u];
+        const TcFeat *const mp = fp + r;
+        me[u] = *mp;
+        // no neighbour (or the agent is out of the game): its own record stands in, so every
+        // difference below is +0.0 without a select
+        const bool valid = ((me[u].type_sig & 1) != 0) && (jq[u] != 0xffffu);
+        nb[u] = *(valid ? l.feat + jq[u] : mp);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool valid = ((me[u].type_sig & 1) != 0) && (jq[u] != 0xffffu);
+        unsigned mv = valid ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(mv));  // (opaque: keeps the AND below from being turned into selects)
+        const unsigned ts = (unsigned)nb[u].type_sig & mv;
+        float *o = stage + mis + off[u];
+        o[0] = (float)(nb[u].nx - me[u].nx);   // float64 difference, narrowed (:560)
+        o[K] = (float)(nb[u].ny - me[u].ny);
+        o[2 * K] = nb[u].nsp - me[u].nsp;      // float32 operands: the float64 difference rounds to this
+        o[3 * K] = nb[u].nac - me[u].nac;
+        o[4 * K] = nb[u].ndir - me[u].ndir;
+        o[5 * K] = __uint_as_float(ts & 0x3f800000u);
+        o[6 * K] = __uint_as_float((0u - (ts & 1u)) & 0x3f800000u);
       }
       if (lane < rc) {
         // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
