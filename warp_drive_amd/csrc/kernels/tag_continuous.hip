@@ -365,7 +365,7 @@ __device__ __forceinline__ bool tc_find_tag(const TcArgs &a, const TcTables &tb,
                                             int *nrun_env, int n_taggers, float my_x, float my_y) {
   float best = __builtin_inff();
   int bt = -1;
-  constexpr int U = 8;  // taggers per batch: all id reads, then all position reads, in flight together
+  constexpr int U = 5;  // taggers per batch: all id reads, then all position reads, in flight together
   for (int t0 = 0; t0 < n_taggers; t0 += U) {
     int j[U];
     float2 pt[U];
@@ -719,10 +719,11 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   return l;
 }
 
-template <int KMAX, bool FUSED>
+// EXACTK: K == KMAX, known at compile time (row offsets become immediates, the K-dependent selects fold away)
+template <int KMAX, bool FUSED, bool EXACTK>
 __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
                                              int n_turn) {
-  const int N = a.N, K = a.K;
+  const int N = a.N, K = EXACTK ? KMAX : a.K;
   const int F = 7 * K + 1;
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int epb = max(1, T_ / N);
@@ -1201,13 +1202,15 @@ __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
-    tc_fast_impl<KM, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
+    if (a.K == KM) tc_fast_impl<KM, false, true>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else tc_fast_impl<KM, false, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }                                                                                            \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     WD_TC_FUSE_PACK();                                                                         \
-    tc_fast_impl<KM, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);          \
+    if (a.K == KM) tc_fast_impl<KM, true, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else tc_fast_impl<KM, true, false>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }
 WD_TC_SPECIALISE(2, 4)
 WD_TC_SPECIALISE(4, 4)
