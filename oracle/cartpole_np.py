@@ -1,11 +1,15 @@
 """numpy oracle for the Cartpole Euler step, batched (test infrastructure).
 
-PARITY UNPINNED: the reference's CPU step is third-party gym.envs.classic_control.
-CartPoleEnv (example_envs/single_agent/classic_control/cartpole/cartpole.py:7,21,29; gym is
-absent and only pinned as gym>=0.26).  This restates the reference's own device kernel,
+The reference's CPU step is third-party gym.envs.classic_control.CartPoleEnv
+(example_envs/single_agent/classic_control/cartpole/cartpole.py:7,21,29; gym is absent and only
+pinned as gym>=0.26).  This restates the reference's own device kernel,
 cartpole_step_numba.py:5-83, with Numba's dtype flow made explicit: float32 state and
 scalars; the Python literal 4.0/3.0 widens the pole-acceleration denominator, thetaacc and
 xacc to float64.  cos/sin are numpy's float32 kernels.
+PINNED against tests/golden/cp_traj.npz: that kernel's source executed under a numba.cuda
+stand-in in the build container (oracle/gen_golden.py::gen_cartpole_traj); floats agree to
+2e-6 abs free-running over whole episodes (the stand-in evaluates cos/sin in float64), discrete
+outputs exactly (tests/test_oracle_golden.py::test_cartpole_oracle_vs_reference_kernel_source).
 """
 import numpy as np
 

@@ -18,7 +18,25 @@ What is recorded
   * tc_traj_*.npz     -- TagContinuous trajectories for the four scenarios of
                           reference tests/example_envs/pycuda_tests/
                           test_tag_continuous.py:15-80 and for the 5x100 K=10
-                          benchmark shape, reference tag_continuous.py:796-887.
+                          benchmark shape, reference tag_continuous.py:796-887
+                          (bench5x100_ep: the same shape with 15-tick episodes, so
+                          episode ends and restarts are recorded from the reference too).
+  * loss_fixtures.npz -- the reference's A2C / PPO `compute_loss_and_metrics`
+                          (training/algorithms/policygradient/a2c.py:40-194, ppo.py:42-228) on
+                          seeded random batches: inputs, loss, every logged metric and the
+                          gradients w.r.t. logits and values.
+  * ref_checkpoint_io.npz -- the reference's shipped policies (tutorials/assets/
+                          tag_continuous_training/{runner,tagger}_1000010000.state_dict) loaded into
+                          the reference's own FullyConnected (models/fully_connected.py:19-93):
+                          tensor names / shapes, file hashes, and the outputs for a seeded input.
+  * cp_traj.npz       -- Cartpole: the reference's OWN device kernel source,
+                          example_envs/single_agent/classic_control/cartpole/
+                          cartpole_step_numba.py:5-83, executed here under a minimal
+                          `numba.cuda` stand-in (jit = identity, blockIdx/threadIdx set by
+                          the driver loop) on float32 numpy arrays.  gym (the reference's
+                          CPU step) is absent, so this is the only reference-run pin the
+                          path has; it runs with Python/numpy scalar semantics, i.e. cos/sin
+                          in float64 rounded to float32 where Numba would call cosf/sinf.
 
 Usage:  python oracle/gen_golden.py          (from the repo root)
 """
@@ -249,8 +267,185 @@ def gen_tag_continuous_traj(tag, cfg, num_envs, num_ticks, action_seed):
     )
 
 
+# --------------------------------------------------------------------------
+# Cartpole: run the reference's Numba kernel SOURCE under a numba.cuda stand-in
+# --------------------------------------------------------------------------
+def gen_cartpole_traj(num_envs=48, num_ticks=130, episode_length=45, action_seed=5000):
+    import importlib.util
+    import types
+
+    class _Idx:
+        x = 0
+
+    stub_cuda = types.ModuleType("numba.cuda")
+    stub_cuda.jit = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    stub_cuda.blockIdx, stub_cuda.threadIdx = _Idx(), _Idx()
+    stub = types.ModuleType("numba")
+    stub.cuda = stub_cuda
+    saved = {k: sys.modules.get(k) for k in ("numba", "numba.cuda")}
+    sys.modules["numba"], sys.modules["numba.cuda"] = stub, stub_cuda
+    try:
+        path = os.path.join(REF, "example_envs/single_agent/classic_control/cartpole/cartpole_step_numba.py")
+        spec = importlib.util.spec_from_file_location("ref_cartpole_step_numba", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    step = mod.NumbaClassicControlCartPoleEnvStep
+    f32 = np.float32
+    # gym's CartPoleEnv constants (gym is absent: stated here as this repo's configuration; the
+    # reference reads them off the gym object, cartpole.py:71-79) -- narrowed to float32 exactly as
+    # the reference's data manager narrows every scalar (data_manager.py:348-351)
+    masscart, masspole, length = 1.0, 0.1, 0.5
+    consts = dict(gravity=f32(9.8), masspole=f32(masspole), total_mass=f32(masspole + masscart), length=f32(length),
+                  polemass_length=f32(masspole * length), force_mag=f32(10.0), tau=f32(0.02),
+                  theta_threshold_radians=f32(12 * 2 * np.pi / 360), x_threshold=f32(2.4))
+    E, T = num_envs, episode_length
+    initial = np.array([0.013, -0.021, 0.034, 0.027], dtype=f32)
+    state = np.tile(initial, (E, 1, 1)).astype(f32)          # [E, 1, 4]
+    action = np.zeros((E, 1, 1), np.int32)
+    done = np.zeros(E, np.int32)
+    reward = np.zeros((E, 1), f32)
+    obs = np.zeros((E, 1, 4), f32)
+    timestep = np.zeros(E, np.int32)
+    rng = np.random.RandomState(action_seed)
+    rec = {k: [] for k in ("actions", "state", "obs", "rewards", "done", "timestep")}
+    for _ in range(num_ticks):
+        action[:] = rng.randint(0, 2, size=(E, 1, 1))
+        for e in range(E):                                   # grid = (E,), block = (1,)
+            stub_cuda.blockIdx.x, stub_cuda.threadIdx.x = e, 0
+            step(state, action, done, reward, obs, consts["gravity"], consts["masspole"], consts["total_mass"],
+                 consts["length"], consts["polemass_length"], consts["force_mag"], consts["tau"],
+                 consts["theta_threshold_radians"], consts["x_threshold"], timestep, T)
+        for k, v in (("actions", action), ("state", state), ("obs", obs), ("rewards", reward), ("done", done),
+                     ("timestep", timestep)):
+            rec[k].append(v.copy())
+        # reset_when_done (reset.cu:9-75 semantics): finished replicas restart from the initial state
+        m = done > 0
+        state[m] = initial
+        obs[m] = initial
+        timestep[m] = 0
+        done[m] = 0
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["initial_state"] = initial
+    out["episode_length"] = np.int32(T)
+    out["constants"] = np.array(json.dumps({k: float(v) for k, v in consts.items()}))
+    np.savez_compressed(os.path.join(OUT, "cp_traj.npz"), **out)
+    print(f"cp_traj.npz: E={E} ticks={num_ticks} dones={int(out['done'].sum())} "
+          f"(timeouts {int((out['timestep'] == T).sum())})")
+
+
+# --------------------------------------------------------------------------
+# A2C / PPO objectives: the reference's compute_loss_and_metrics on random batches
+# --------------------------------------------------------------------------
+def gen_loss_fixtures():
+    import torch
+    from warp_drive.training.algorithms.policygradient.a2c import A2C
+    from warp_drive.training.algorithms.policygradient.ppo import PPO
+
+    T, E, n, heads = 12, 6, 3, (5, 7)
+    cases = {
+        "a2c_plain": ("A2C", dict(discount_factor_gamma=0.98, vf_loss_coeff=0.01, entropy_coeff=0.05), 0, -1),
+        "a2c_norm_sched": ("A2C", dict(discount_factor_gamma=0.95, normalize_advantage=True, normalize_return=True,
+                                       vf_loss_coeff=[[0, 1.0], [1000, 0.1]],
+                                       entropy_coeff=[[0, 0.5], [500, 0.05], [2000, 0.01]]), 750, -1),
+        "ppo_plain": ("PPO", dict(discount_factor_gamma=1.0, clip_param=0.1, vf_loss_coeff=1.0, entropy_coeff=0.0), 10, -1),
+        "ppo_norm": ("PPO", dict(discount_factor_gamma=0.9, clip_param=0.3, normalize_advantage=True,
+                                 normalize_return=True, vf_loss_coeff=0.5, entropy_coeff=[[0, 0.1], [100, 0.0]]), 40, -1),
+        "a2c_posneg": ("A2C", dict(discount_factor_gamma=0.99, vf_loss_coeff=0.2, entropy_coeff=0.01), 5, 1),
+    }
+    out = {}
+    meta = {}
+    for ci, (name, (algo, kw, timestep, ratio)) in enumerate(cases.items()):
+        g = torch.Generator().manual_seed(9000 + ci)
+        logits = [torch.randn(T, E, n, a, generator=g, dtype=torch.float32) for a in heads]
+        values = torch.randn(T, E, n, generator=g, dtype=torch.float32)
+        actions = torch.stack([torch.randint(0, a, (T, E, n), generator=g) for a in heads], dim=-1)
+        rewards = torch.randn(T, E, n, generator=g, dtype=torch.float32) * 2.0
+        done = (torch.rand(T, E, generator=g) < 0.15).to(torch.int32)
+        done[-1, ::2] = 1                       # some replicas finish on the last row, some bootstrap
+        if ratio > 0:
+            done[3, 1] = 2                      # one replica "reached the goal"
+            done[7, 4] = 2
+        for x in logits:
+            x.requires_grad_(True)
+        values.requires_grad_(True)
+        probs = [torch.softmax(x, dim=-1) for x in logits]
+        trainer = (A2C if algo == "A2C" else PPO)(**kw)
+        np.random.seed(1234 + ci)               # the positive/negative down-sampling draws from np.random
+        loss, metrics = trainer.compute_loss_and_metrics(
+            timestep=timestep, actions_batch=actions, rewards_batch=rewards, done_flags_batch=done,
+            action_probabilities_batch=probs, value_functions_batch=values, perform_logging=True,
+            negative_positive_ratio=ratio)
+        loss.backward()
+        for h, x in enumerate(logits):
+            out[f"{name}.logits{h}"] = x.detach().numpy()
+            out[f"{name}.grad_logits{h}"] = x.grad.numpy()
+        out[f"{name}.values"] = values.detach().numpy()
+        out[f"{name}.grad_values"] = values.grad.numpy()
+        out[f"{name}.actions"] = actions.numpy()
+        out[f"{name}.rewards"] = rewards.numpy()
+        out[f"{name}.done"] = done.numpy()
+        out[f"{name}.loss"] = np.float64(loss.item())
+        meta[name] = {"algo": algo, "kwargs": kw, "timestep": timestep, "negative_positive_ratio": ratio,
+                      "np_seed": 1234 + ci, "metrics": {k: float(v) for k, v in metrics.items()}}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "loss_fixtures.npz"), **out)
+    print(f"loss_fixtures.npz: {len(cases)} cases from the reference's A2C / PPO compute_loss_and_metrics")
+
+
+# --------------------------------------------------------------------------
+# Checkpoint wire format: the reference's shipped TagContinuous policies through ITS model class
+# --------------------------------------------------------------------------
+def gen_checkpoint_fixture():
+    import hashlib
+    import types
+
+    import torch
+    import yaml
+    from warp_drive.training.models.fully_connected import FullyConnected
+
+    assets = os.path.join(REF, "tutorials/assets/tag_continuous_training")
+    cfg = yaml.safe_load(open(os.path.join(assets, "run_config.yaml")))
+    env = TagContinuous(**cfg["env"])
+    wrapper = EnvWrapper(env_obj=env, env_backend="cpu")        # fills env.observation_space
+    policy_map = {"tagger": sorted(env.taggers), "runner": sorted(env.runners)}
+    # the model constructor only asks the data manager for the batch placeholder's leading dimension
+    wrapper.cuda_data_manager = types.SimpleNamespace(get_shape=lambda name: (1,))
+    out, manifest = {}, {}
+    g = torch.Generator().manual_seed(77)
+    obs = torch.randn(3, 6, 71, generator=g, dtype=torch.float32)
+    out["obs"] = obs.numpy()
+    for pol in ("runner", "tagger"):
+        path = os.path.join(assets, f"{pol}_1000010000.state_dict")
+        sd = torch.load(path, map_location="cpu")
+        model = FullyConnected(wrapper, cfg["policy"][pol]["model"], pol, policy_map)
+        model.load_state_dict(sd)                                # strict: the reference's own format
+        model.eval()
+        with torch.no_grad():
+            probs, vals = model(obs)
+        for h, p in enumerate(probs):
+            out[f"{pol}.probs{h}"] = p.numpy()
+        out[f"{pol}.values"] = vals.numpy()
+        manifest[pol] = {"file": f"tutorials/assets/tag_continuous_training/{pol}_1000010000.state_dict",
+                         "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(),
+                         "tensors": {k: list(v.shape) for k, v in sd.items()},
+                         "fc_dims": cfg["policy"][pol]["model"]["fc_dims"],
+                         "head_sizes": [int(p.shape[-1]) for p in probs], "obs_size": 71}
+    out["manifest"] = np.array(json.dumps(manifest))
+    np.savez_compressed(os.path.join(OUT, "ref_checkpoint_io.npz"), **out)
+    print("ref_checkpoint_io.npz: runner/tagger_1000010000.state_dict through the reference's FullyConnected")
+
+
 def main():
     gen_gridworld_kat()
+    gen_cartpole_traj()
+    gen_loss_fixtures()
+    gen_checkpoint_fixture()
 
     gw = dict(num_taggers=4, grid_length=4, episode_length=20, seed=27, wall_hit_penalty=0.1,
               tag_reward_for_tagger=10.0, tag_penalty_for_runner=2.0, step_cost_for_tagger=0.01)
@@ -312,6 +507,8 @@ def main():
                      end_of_game_reward_for_runner=1.0, runner_exits_game_after_tagged=True)
     gen_tag_continuous_traj("bench5x100", bench_cfg, 2, 12, 3000)
     gen_tag_continuous_traj("bench5x100_full", dict(bench_cfg, use_full_observation=True), 1, 3, 3100)
+    # the bench shape through episode ends and restarts (15-tick episodes, 3 episodes)
+    gen_tag_continuous_traj("bench5x100_ep", dict(bench_cfg, episode_length=15), 2, 47, 3200)
 
 
 if __name__ == "__main__":

@@ -319,8 +319,8 @@ def test_function_manager_testkernel_and_log():
 
 
 def test_cartpole_vs_oracle():
-    """BASELINE config[5] kernel against the numpy restatement of cartpole_step_numba.py
-    (parity unpinned: the reference's CPU step is third-party gym)."""
+    """BASELINE config[5] kernel against the numpy restatement of cartpole_step_numba.py, bit-exact
+    at E = 5000 (the restatement itself is pinned by tests/golden/cp_traj.npz)."""
     from oracle.cartpole_np import CartPoleOracle
     from tests.hip_harness import OBS, REW, make_wrapper, pull, push_actions, require_gpu
     from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
@@ -343,6 +343,39 @@ def test_cartpole_vs_oracle():
         w.reset_only_done_envs()
         orc.reset_done_envs()
         np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)
+
+
+def test_cartpole_vs_reference_kernel_source():
+    """The device kernel replays tests/golden/cp_traj.npz -- the reference's own Numba kernel source
+    (cartpole_step_numba.py:5-83) run under a numba.cuda stand-in in the build container
+    (oracle/gen_golden.py::gen_cartpole_traj): same initial state, same action stream, free-running
+    through terminations, time-outs and restarts.  Floats within 1e-5 abs (the stand-in evaluates
+    cos/sin in float64; observed ~2e-6), everything discrete exact."""
+    import os
+
+    from tests.hip_harness import OBS, REW, make_wrapper, pull, push_actions, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+
+    require_gpu()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cp_traj.npz"))
+    ticks, E = g["actions"].shape[:2]
+    env = CUDAClassicControlCartPoleEnv(episode_length=int(g["episode_length"]), seed=1,
+                                        initial_state=g["initial_state"])  # the fixture's start state
+    w = make_wrapper(env, E)
+    np.testing.assert_array_equal(pull(w, "state")[0, 0], g["initial_state"])
+    worst = 0.0
+    for t in range(ticks):
+        push_actions(w, g["actions"][t].astype(np.int32))
+        w.step_all_envs()
+        st = pull(w, "state")
+        worst = max(worst, float(np.abs(st - g["state"][t]).max()))
+        np.testing.assert_allclose(st, g["state"][t], rtol=0, atol=1e-5, err_msg=f"t={t}")
+        np.testing.assert_allclose(pull(w, OBS), g["obs"][t], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(pull(w, "_done_"), g["done"][t])
+        np.testing.assert_array_equal(pull(w, "_timestep_"), g["timestep"][t])
+        np.testing.assert_array_equal(pull(w, REW), g["rewards"][t])
+        w.reset_only_done_envs()
+    assert worst < 1e-5
 
 
 @pytest.mark.parametrize("ticks", [1, 4])

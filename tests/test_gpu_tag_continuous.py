@@ -88,7 +88,7 @@ def _run_lockstep(cfg, E, ticks, seed, stats=None):
     return stats
 
 
-TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full"]
+TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep"]
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)

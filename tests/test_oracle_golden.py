@@ -62,7 +62,7 @@ def test_gridworld_trajectory(golden_dir, tag):
 
 
 # --------------------------------------------------------------- TagContinuous
-TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full"]
+TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep"]
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)
@@ -201,3 +201,31 @@ def test_philox_known_answers():
         assert tuple(int(g) for g in got) == want
     u = u01_open_closed(np.array([0, 0xFFFFFFFF, 0x80000000], dtype=np.uint32))
     assert u.dtype == np.float32 and u[0] == np.float32(2.0 ** -24) and u[1] == 1.0 and u[2] == np.float32(0.5) + np.float32(2.0 ** -24)
+
+
+CP_TOL = 1e-5  # absolute, on positions / velocities / angles of O(1)
+
+
+def test_cartpole_oracle_vs_reference_kernel_source(golden_dir):
+    """tests/golden/cp_traj.npz = the reference's cartpole_step_numba.py:5-83 executed under a
+    numba.cuda stand-in (oracle/gen_golden.py::gen_cartpole_traj).  The oracle restates Numba's dtype
+    flow (cosf/sinf, float64 promotion through the 4.0/3.0 literal), the stand-in runs the same source with
+    Python/numpy scalars -- so floats agree to rounding (observed 1.9e-6 free-running over whole
+    episodes), and timesteps, terminations and rewards agree exactly."""
+    from oracle.cartpole_np import CartPoleOracle
+
+    g = np.load(os.path.join(golden_dir, "cp_traj.npz"))
+    ticks, E = g["actions"].shape[:2]
+    orc = CartPoleOracle(E, int(g["episode_length"]), initial_state=g["initial_state"])
+    worst = 0.0
+    for t in range(ticks):
+        orc.step(g["actions"][t])
+        worst = max(worst, float(np.abs(orc.state - g["state"][t][:, 0]).max()))
+        np.testing.assert_allclose(orc.state, g["state"][t][:, 0], rtol=0, atol=CP_TOL, err_msg=f"t={t}")
+        np.testing.assert_allclose(orc.obs, g["obs"][t][:, 0], rtol=0, atol=CP_TOL)
+        np.testing.assert_array_equal(orc.done, g["done"][t])
+        np.testing.assert_array_equal(orc.timestep, g["timestep"][t])
+        np.testing.assert_array_equal(orc.rewards, g["rewards"][t][:, 0])
+        orc.reset_done_envs()
+    assert int(g["done"].sum()) > 200 and int((g["timestep"] == int(g["episode_length"])).sum()) > 0
+    assert worst < CP_TOL

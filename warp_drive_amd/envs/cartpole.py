@@ -4,8 +4,9 @@ Host-side mirror of reference example_envs/single_agent/classic_control/cartpole
 cartpole.py:19-141 and single_agent/base.py.  The reference's CPU step delegates to
 third-party `gym.envs.classic_control.CartPoleEnv` (absent here); this class carries the
 classic constants itself and its CPU step is the same Euler update the reference's device
-kernel implements (cartpole_step_numba.py:29-83).  Parity for Cartpole is therefore
-"unpinned" (DESIGN.md).  The device step launches `HipClassicControlCartPoleEnvStep`.
+kernel implements (cartpole_step_numba.py:29-83).  Parity is pinned by a trajectory recorded from
+that kernel source run under a numba.cuda stand-in (tests/golden/cp_traj.npz).
+The device step launches `HipClassicControlCartPoleEnvStep`.
 """
 import math
 
@@ -57,7 +58,10 @@ def euler_step(state, action, p=CartPolePhysics):
 class ClassicControlCartPoleEnv:
     name = "ClassicControlCartPoleEnv"
 
-    def __init__(self, episode_length=500, env_backend="cpu", reset_pool_size=0, seed=None):
+    def __init__(self, episode_length=500, env_backend="cpu", reset_pool_size=0, seed=None, initial_state=None):
+        """`initial_state` (optional, beyond the reference's signature): a fixed start state instead of
+        the seeded draw -- the golden-trajectory tests start from the fixture's."""
+        self.initial_state = None if initial_state is None else np.asarray(initial_state, dtype=np.float32)
         self.num_agents = 1
         self.agents = {0: True}
         assert episode_length > 0
@@ -75,6 +79,8 @@ class ClassicControlCartPoleEnv:
         self.state = None
 
     def _draw_initial_state(self, fixed):
+        if fixed and self.initial_state is not None:
+            return np.asarray(self.initial_state, dtype=np.float32).copy()
         rng = np.random.default_rng(self.seed) if fixed else self._rng
         return rng.uniform(low=-0.05, high=0.05, size=(4,)).astype(np.float32)
 

@@ -5,6 +5,7 @@ normalisation across the (env, agent) dimensions.
 
 Batches are [T, E, n(, heads)] tensors that live on the device; nothing here touches the host
 unless `perform_logging` asks for metric scalars."""
+import numpy as np
 import torch
 from torch import nn
 from torch.distributions import Categorical
@@ -43,9 +44,36 @@ class A2C:
     def _policy_loss(self, log_prob, advantages):
         return (-log_prob * advantages).mean()
 
+    @staticmethod
+    def _sample_positive_negative_env_ids(done_flags_batch, negative_positive_ratio):
+        """replicas that ended by reaching the goal (done == 2) are "positives"; keep all of them and a
+        random `ratio` x as many of the others (a2c.py:196-220)"""
+        positives = torch.any(done_flags_batch == 2, dim=0)
+        positive_env_ids = positives.nonzero(as_tuple=True)[0].tolist()
+        negative_env_ids = (~positives).nonzero(as_tuple=True)[0].tolist()
+        pos_size = len(positive_env_ids)
+        if pos_size > 0:
+            neg_size = int(pos_size * negative_positive_ratio)
+            if pos_size + neg_size < done_flags_batch.shape[1]:
+                chosen = np.random.choice(negative_env_ids, size=neg_size, replace=False).tolist()
+                return positive_env_ids, chosen, True
+        return positive_env_ids, negative_env_ids, False
+
     def compute_loss_and_metrics(self, timestep=None, actions_batch=None, rewards_batch=None,
                                  done_flags_batch=None, action_probabilities_batch=None,
-                                 value_functions_batch=None, perform_logging=False):
+                                 value_functions_batch=None, perform_logging=False, negative_positive_ratio=-1):
+        assert timestep is not None and actions_batch is not None and rewards_batch is not None
+        assert done_flags_batch is not None and action_probabilities_batch is not None
+        assert value_functions_batch is not None
+        pos_env_ids = neg_env_ids = None
+        if negative_positive_ratio > 0:
+            pos_env_ids, neg_env_ids, need_downsample = self._sample_positive_negative_env_ids(
+                done_flags_batch, negative_positive_ratio)
+            if need_downsample:
+                keep = pos_env_ids + neg_env_ids
+                actions_batch, rewards_batch = actions_batch[:, keep], rewards_batch[:, keep]
+                done_flags_batch, value_functions_batch = done_flags_batch[:, keep], value_functions_batch[:, keep]
+                action_probabilities_batch = [p[:, keep] for p in action_probabilities_batch]
         values_detached = value_functions_batch.detach()
         returns = discounted_returns(rewards_batch, done_flags_batch, values_detached, self.discount_factor_gamma)
         norm_returns = _normalise(returns) if self.normalize_return else returns
@@ -76,6 +104,16 @@ class A2C:
                 "Mean normalized returns": norm_returns.mean().item(), "Mean entropy": mean_entropy.item(),
                 "Variance explained by the value function": var_explained.item(),
             }
+            # mean of the standard deviation of the sampled actions (a2c.py:160-180)
+            af = actions_batch.float()
+            over_agents, over_time, over_envs = (af.std(dim=d).mean(dim=(0, 1)) for d in (2, 0, 1))
+            for h in range(af.shape[-1]):
+                metrics[f"Std. of action_{h} over agents"] = over_agents[h].item()
+                metrics[f"Std. of action_{h} over envs"] = over_envs[h].item()
+                metrics[f"Std. of action_{h} over time"] = over_time[h].item()
+            if negative_positive_ratio > 0:
+                metrics["Num of Positive Sampled Envs"] = len(pos_env_ids)
+                metrics["Num of Negative Sampled Envs"] = len(neg_env_ids)
         return loss, metrics
 
 
