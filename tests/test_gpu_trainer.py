@@ -106,3 +106,55 @@ def test_graph_and_eager_rollouts_agree(tmp_path):
         trainer.graceful_close()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_fetch_episode_states_matches_the_oracle(tmp_path):
+    """f4: Trainer.fetch_episode_states (reference trainer_base.py:689-792) -- one replica's states,
+    actions and rewards for a whole episode, logged on the device by HIPLogController and pulled once.
+    The logged actions are replayed through the oracle from the same seeded start state: positions,
+    flags and rewards must match bit-exactly at every tick, and the log must stop at the episode end."""
+    import numpy as np
+    import yaml
+
+    from oracle.tag_continuous_np import TagContinuousOracle
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.training.scripts import train as train_script
+    from warp_drive_amd.training.scripts.train import setup_trainer
+
+    require_gpu()
+    ov = {"trainer": {"num_envs": 16, "train_batch_size": 16 * 10, "num_episodes": 40, "seed": 11},
+          "env": {"num_runners": 14, "episode_length": 25, "num_other_agents_observed": 5, "tagging_distance": 0.3},
+          "saving": {"metrics_log_freq": 100, "model_params_save_freq": 0}}
+    trainer = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path), verbose=False)
+    trainer.train(1)
+    names = ["loc_x", "loc_y", "still_in_the_game"]
+    env_id = 5
+    states, actions, rewards, probs = trainer.fetch_episode_states(
+        names, env_id=env_id, include_rewards_actions=True, include_probabilities=True)
+    T = trainer.w.episode_length
+    assert set(states) == set(names) and states["loc_x"].shape == (T + 1, trainer.w.n_agents)
+    assert actions.shape == (T, trainer.w.n_agents, 2) and rewards.shape == (T, trainer.w.n_agents)
+    assert states["loc_x"].dtype == np.float64
+    # replay through the oracle
+    cfg = yaml.safe_load(open(os.path.join(train_script._CONFIGS, "tag_continuous.yaml")))["env"]
+    cfg.update(ov["env"])
+    orc = TagContinuousOracle(num_envs=1, **cfg)
+    np.testing.assert_array_equal(states["loc_x"][0], orc.loc_x[0].astype(np.float64))
+    end = None
+    for t in range(T):
+        orc.step(actions[t][None].astype(np.int32))
+        np.testing.assert_array_equal(states["loc_x"][t + 1], orc.loc_x[0], err_msg=f"t={t}")
+        np.testing.assert_array_equal(states["loc_y"][t + 1], orc.loc_y[0])
+        np.testing.assert_array_equal(states["still_in_the_game"][t + 1], orc.sig[0])
+        np.testing.assert_array_equal(rewards[t], orc.rewards[0])
+        assert set(probs[t]) == {"runner", "tagger"} and len(probs[t]["runner"]) == 2
+        if orc.done[0]:
+            end = t + 1
+            break
+    assert end is not None and end <= T
+    assert np.isnan(states["loc_x"][end + 1:]).all() and (rewards[end:] == 0).all()
+    assert max(probs) == end - 1
+    # a second call restarts from the seeded state: same start row
+    again = trainer.fetch_episode_states(["loc_x"], env_id=0)
+    np.testing.assert_array_equal(again["loc_x"][0], states["loc_x"][0])
+    trainer.graceful_close()

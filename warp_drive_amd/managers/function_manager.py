@@ -587,10 +587,57 @@ class HIPEnvironmentReset(CUDAEnvironmentReset):
 
 
 class HIPLogController(CUDALogController):
-    """Replaces PyCUDALogController (pycuda_function_manager.py:399-483)."""
+    """Replaces PyCUDALogController (pycuda_function_manager.py:399-483).
+
+    Besides the arrays registered with `log_data_across_episode=True` (logged by the
+    `log_one_step_*` kernels), any device array can be attached after the fact with
+    `attach_states()`: its replica slice is then copied device-to-device into a `[T + 1, ...]` buffer
+    every step -- what `Trainer.fetch_episode_states` uses instead of the reference's per-tick host
+    pulls (trainer_base.py:689-792)."""
 
     def __init__(self, function_manager: HIPFunctionManager):
         super().__init__(function_manager)
+        self._attached = {}  # name -> (DevicePtr of [T + 1, row...], row shape, dtype, row bytes)
+
+    def attach_states(self, data_manager, names):
+        T = int(data_manager.meta_info("episode_length"))
+        for name in names:
+            if name in data_manager.log_data_list or name in self._attached:
+                continue
+            assert data_manager.is_data_on_device(name), f"{name} is not a valid array name on the GPU!"
+            shape = tuple(data_manager.get_shape(name))
+            assert shape[0] == int(data_manager.meta_info("n_envs")), "log assumes the 0th dimension is n_envs"
+            dtype = np.dtype(data_manager.get_dtype(name))
+            row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * dtype.itemsize if len(shape) > 1 else dtype.itemsize
+            buf = drv.mem_alloc(max(row_bytes * (T + 1), 8))
+            self._attached[name] = (buf, shape[1:], dtype, row_bytes)
+
+    def _log_attached(self, data_manager, step, env_id):
+        for name, (buf, _, _, row_bytes) in self._attached.items():
+            src = int(data_manager.device_data(name)) + int(env_id) * row_bytes
+            drv.memcpy_dtod(int(buf) + int(step) * row_bytes, src, row_bytes)
+
+    def fetch_log(self, data_manager, names=None, last_step=None, check_last_valid_step=True):
+        registered = [n for n in (data_manager.log_data_list if names is None else names)
+                      if n in data_manager.log_data_list]
+        out = super().fetch_log(data_manager, registered, last_step, check_last_valid_step)
+        upto = last_step if (last_step is not None and last_step <= self.last_valid_step) else self.last_valid_step
+        T = int(data_manager.meta_info("episode_length"))
+        for name in (self._attached if names is None else [n for n in names if n in self._attached]):
+            buf, row_shape, dtype, row_bytes = self._attached[name]
+            host = np.empty((T + 1, *row_shape), dtype=dtype)
+            drv.synchronize()
+            if host.nbytes:
+                drv.memcpy_dtoh(host, buf)
+            out[f"{name}_for_log"] = host[: upto + 1]
+        return out
+
+    def __del__(self):
+        for buf, *_ in getattr(self, "_attached", {}).values():
+            try:
+                buf.free()
+            except Exception:
+                pass
 
     def _log_one_step(self, data_manager, step: int, env_id: int = 0):
         assert env_id < data_manager.meta_info("n_envs")
@@ -611,6 +658,7 @@ class HIPLogController(CUDALogController):
             fn(data_manager.device_data(f"{name}_for_log"), data_manager.device_data(name), np.int32(feature_dim),
                np.int32(step), data_manager.meta_info("episode_length"), np.int32(env_id),
                data_manager.meta_info("n_agents"), block=(256, 1, 1), grid=(max(1, min(64, (row + 255) // 256)), 1))
+        self._log_attached(data_manager, step, env_id)
 
     def _update_log_mask(self, data_manager, step: int):
         fn = self._function_manager.get_function("update_log_mask")

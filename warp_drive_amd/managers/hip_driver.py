@@ -216,6 +216,12 @@ def memcpy_dtoh(host_array, src, stream=None):
                                _vp(current_stream() if stream is None else stream)), "wd_memcpy_dtoh")
 
 
+def memcpy_dtod(dst, src, nbytes, stream=None):
+    """device -> device, asynchronous on the stream torch is using"""
+    _check(_lib.wd_memcpy_dtod(_vp(int(dst)), _vp(int(src)), int(nbytes),
+                               _vp(current_stream() if stream is None else stream)), "wd_memcpy_dtod")
+
+
 def memset(dst, byte_value, nbytes, stream=None):
     _check(_lib.wd_memset(_vp(int(dst)), int(byte_value), int(nbytes),
                           _vp(current_stream() if stream is None else stream)), "wd_memset")

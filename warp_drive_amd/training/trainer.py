@@ -348,6 +348,89 @@ class Trainer:
             except ValueError:
                 pass
 
+    # ------------------------------------------------------------------- evaluation (f4)
+    @torch.no_grad()
+    def _policy_probabilities(self):
+        """policy forward on the current observations; fills the [E, N, A_h] tensors the sampler reads
+        and returns {policy: [per-head probabilities of its agents]}"""
+        flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
+        out = {}
+        for pol in self.policies:
+            ids = self.ids[pol]
+            obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
+            probs, _ = self._inference_model(pol)(obs_p)
+            out[pol] = probs
+            for h, p in enumerate(probs):
+                if len(self.policies) == 1:
+                    self.probs[h].copy_(p)
+                else:
+                    self.probs[h].index_copy_(1, ids, p)
+        return out
+
+    def fetch_episode_states(self, list_of_states=None, env_id=0, include_rewards_actions=False,
+                             include_probabilities=False, policy="", **sample_params):
+        """Step through one episode with the trained policies and return the requested device arrays of
+        replica `env_id` for every tick (reference trainer_base.py:689-792: same arguments and return
+        values; arrays are float64 [T + 1, ...] with NaN after the episode's end).
+
+        The reference pulls every requested array to the host on every tick; here the replica's slices
+        are copied device-to-device into [T + 1, ...] buffers by the episode logger
+        (HIPLogController.attach_states) and pulled once at the end.  The tick is sample -> step WITHOUT
+        the reset of finished replicas, so the terminal state is observable, as in the reference."""
+        from warp_drive_amd.managers.function_manager import HIPLogController, _stream_tag
+
+        assert 0 <= env_id < self.num_envs
+        list_of_states = [] if list_of_states is None else list_of_states
+        assert isinstance(list_of_states, list)
+        dm, w = self.w.cuda_data_manager, self.w
+        T, H = w.episode_length, len(self.head_sizes)
+        w.reset_all_envs()  # every replica restarts; done flags are cleared
+        logger = HIPLogController(w.cuda_function_manager)
+        for state in list_of_states:
+            assert dm.is_data_on_device(state), f"{state} is not a valid array name on the GPU!"
+        extra = [n for n in ((_ACTIONS, _REWARDS) if include_rewards_actions else ()) if n not in list_of_states]
+        logger.attach_states(dm, list_of_states + ["_done_"] + extra)
+        logger.reset_log(dm, env_id=env_id)  # logs s_0
+        actions_ptr = dm.device_data(_ACTIONS)
+        E, N = self.num_envs, w.n_agents
+        episode_probabilities, end = {}, T
+        # rewards / actions of tick t live in row t + 1 of the log (they are written by the step)
+        for t in range(T):
+            probabilities = self._policy_probabilities()
+            for h, (p, a) in enumerate(zip(self.probs, self.head_sizes)):
+                fn, args, block, grid, shared = self.sampler.categorical_launch(
+                    p, actions_ptr, E * N, a, bool(sample_params.get("use_argmax", False)),
+                    _stream_tag(f"{_ACTIONS}_{h}"), out_stride=H, out_offset=h)
+                fn(*args, block=block, grid=grid, shared=shared)
+            w.step_all_envs()
+            logger.update_log(dm, t + 1)  # s_{t+1} (and a_t, r_{t+1}, done)
+            if include_probabilities:
+                sel = {policy: probabilities[policy]} if len(policy) > 0 else probabilities
+                episode_probabilities[t] = {pol: [p[env_id].detach().cpu().numpy() for p in ps]
+                                            for pol, ps in sel.items()}
+        log = logger.fetch_log(dm, check_last_valid_step=False)
+        done = log["_done__for_log"]
+        finished = np.flatnonzero(done[1:] > 0)
+        if len(finished):
+            end = int(finished[0]) + 1  # the tick whose step finished the episode
+        episode_states = {}
+        for state in list_of_states:
+            full = np.full((T + 1, *dm.get_shape(state)[1:]), np.nan, dtype=np.float64)
+            full[: end + 1] = log[f"{state}_for_log"][: end + 1]
+            episode_states[state] = full
+        if include_probabilities:
+            episode_probabilities = {t: p for t, p in episode_probabilities.items() if t < end}
+        if not include_rewards_actions:
+            return episode_states
+        ids = self.policy_map[policy] if len(policy) > 0 else list(range(N))
+        acts = np.zeros((T, len(ids), *dm.get_shape(_ACTIONS)[2:]), dtype=dm.get_dtype(_ACTIONS))
+        rews = np.zeros((T, len(ids)), dtype=np.float32)
+        acts[:end] = log[f"{_ACTIONS}_for_log"][1: end + 1][:, ids]
+        rews[:end] = log[f"{_REWARDS}_for_log"][1: end + 1][:, ids]
+        if include_probabilities:
+            return episode_states, acts, rews, episode_probabilities
+        return episode_states, acts, rews
+
     def graceful_close(self):
         torch.cuda.synchronize()
         wdd.barrier()
