@@ -134,9 +134,6 @@ def main():
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="Cartpole only: env ticks fused into one launch (fixed-policy rollout; SURVEY 8(d) "
                          "asks the ceiling run to fuse T ticks); a bench 'step' is then one launch = T ticks")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="replica groups on separate HIP streams (fused tick only): overlaps the memory-bound "
-                         "phases of one group with the neighbour search of another")
     ap.add_argument("--unfused", action="store_true",
                     help="tick = 4 launches (sample x2, step, fused reset) instead of the single tick kernel")
     args = ap.parse_args()
@@ -195,8 +192,7 @@ def main():
     seeds = wdd.gather_ints(seed)
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
-    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused,
-                           n_groups=args.groups)
+    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused)
     steps, warmup = args.steps, args.warmup
     if args.mode == "graph":
         steps = max(10, steps // 10 * 10)
@@ -287,7 +283,7 @@ def main():
                             f"{'s' if len(engine.head_sizes) > 1 else ''}) + step"
                             f"{'' if args.no_reset else ' + reset of finished replicas'}"
                             f"{' (one fused launch)' if engine.fused else ''}",
-                "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode, "replica_groups": args.groups,
+                "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode,
                 "kernels_per_tick": len(engine.entry_names), "ticks_per_launch": engine.ticks_per_launch,
                 "parallelism": f"env-replica sharding x{world}", "sampler_seeds": seeds,
             },

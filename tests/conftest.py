@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# Near-tie accounting of the TagContinuous parity tests (tests/test_gpu_tag_continuous.py): the only
+# tolerated deviation from the oracle is an observation row whose K-th and (K+1)-th neighbour distances
+# agree to <= 2 ulp (libm powf(x, 2) in the reference vs x * x here).  Every comparison adds to these
+# totals; they are printed at the end of the session (and kept in DESIGN.md).
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    from tests.hip_harness import NEAR_TIE_TOTALS
+
+    if NEAR_TIE_TOTALS["rows"]:
+        terminalreporter.write_line(
+            f"TagContinuous parity: {NEAR_TIE_TOTALS['near_tie_rows']} near-tie observation rows out of "
+            f"{NEAR_TIE_TOTALS['rows']} compared (all other rows bit-exact)")

@@ -41,3 +41,7 @@ def ulp_diff(a, b):
     a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
     b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
     return np.abs(a - b)
+
+
+# session-wide totals of the TagContinuous parity comparisons (see tests/conftest.py)
+NEAR_TIE_TOTALS = {"near_tie_rows": 0, "rows": 0}

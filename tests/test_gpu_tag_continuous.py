@@ -23,6 +23,9 @@ STATE = (("loc_x", "loc_x"), ("loc_y", "loc_y"), ("speed", "speed"), ("direction
          ("edge_hit_reward_penalty", "edge_pen"), ("num_runners", "num_runners"), ("_timestep_", "timestep"))
 
 
+from tests.hip_harness import NEAR_TIE_TOTALS as _TOTALS  # noqa: E402
+
+
 def _mk(cfg, E):
     from tests.hip_harness import make_wrapper, require_gpu
     from warp_drive_amd.envs.tag_continuous import TagContinuous
@@ -58,7 +61,9 @@ def _compare(w, orc, tag, stats):
         assert not orc.use_full_observation, f"full-obs mismatch {tag}: {bad[:5]}"
         assert _near_tie_rows(orc, bad), f"obs mismatch that is not a near-tie {tag}: {bad[:5]}"
         stats["near_tie_rows"] += len(bad)
+        _TOTALS["near_tie_rows"] += len(bad)
     stats["rows"] += obs_ref.shape[0] * obs_ref.shape[1]
+    _TOTALS["rows"] += obs_ref.shape[0] * obs_ref.shape[1]
 
 
 def _run_lockstep(cfg, E, ticks, seed, stats=None):

@@ -267,14 +267,6 @@ __global__ void log_one_step_in_int(int *log, const int *data, int feature_dim, 
               episode_length, env_id);
 }
 
-// ------------------------------------------------------------- math self-test hook
-// Holds a stream for `ticks_10ns` x 10 ns (constant 100 MHz counter): used once, to start
-// replica groups on concurrent streams out of phase with each other (rollout.py).
-__global__ void wd_delay(unsigned long long ticks_10ns) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_10ns) __builtin_amdgcn_s_sleep(8);
-}
-
 // Write-bandwidth probe (scripts/write_pattern_probe.py): every block streams `floats_per_block`
 // floats into its own contiguous slice of `out` (slice b starts at b * slice_stride floats), `vec`
 // floats per lane per store (1 or 4).  Shows what the HBM write path gives to the rollout's access
@@ -290,6 +282,7 @@ __global__ void wd_write_probe(float *out, long slice_stride, int floats_per_blo
   }
 }
 
+// ------------------------------------------------------------- math self-test hook
 // Evaluates the device restatements of numpy's float32 routines so the GPU parity
 // suite can compare them bit-for-bit with numpy on the host (tests/test_gpu_math.py).
 __global__ void wd_test_math(const float *__restrict__ a, const float *__restrict__ b,

@@ -14,8 +14,6 @@ fixed LaunchPlan replayed from C (or captured once into a hipGraph):
 The probability tensors the sampler reads are whatever the policy wrote last (torch
 tensors aliased in place); for kernel-only throughput they are constant uniform tensors.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -28,8 +26,7 @@ _ACTIONS = Constants.ACTIONS
 
 
 class RolloutEngine:
-    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
-                 n_groups=1):
+    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform."""
         assert env_wrapper.env_backend == "hip"
@@ -63,7 +60,6 @@ class RolloutEngine:
                           and H == getattr(env_wrapper.env, "TICK_HEADS", 2)
                           and len(dm.reset_target_to_pool) == 0
                           and getattr(env_wrapper.env, "can_fuse_tick", lambda: True)())
-        self.group_plans, self.group_streams = [], []
         # env ticks per launch (> 1 only for envs whose fused kernel loops over ticks, fixed policy)
         self.ticks_per_launch = int(getattr(env_wrapper.env, "ticks_per_launch", 1)) if self.fused else 1
         if self.fused:
@@ -74,20 +70,6 @@ class RolloutEngine:
             self.step_entry = 0
             self.step_kernel_name = fn.name
             self.entry_names.append(fn.name)
-            if n_groups > 1:
-                # Replica groups on separate HIP streams: every group runs its own chain of tick
-                # kernels, so the memory-bound phases of one group (probability reads, observation
-                # writes) overlap the compute-bound neighbour search of another instead of all
-                # blocks marching through the phases in lock step.
-                from warp_drive_amd.distributed import shard_replicas
-
-                for g in range(n_groups):
-                    first, count = shard_replicas(E, n_groups, g)
-                    plan = drv.LaunchPlan()
-                    plan.add(*self._with_shared(env_wrapper.env.tick_launch(
-                        sampler, probabilities, env_wrapper.env_resetter, env_range=(first, first + count))))
-                    self.group_plans.append(plan)
-                    self.group_streams.append(torch.cuda.Stream(device=dev))
             return
         for k, (p, a) in enumerate(zip(probabilities, head_sizes)):
             fn, args, block, grid, shared = sampler.categorical_launch(
@@ -104,27 +86,8 @@ class RolloutEngine:
             self.plan.add(fn, args, block, grid, 0)
             self.entry_names.append(fn.name)
 
-    @staticmethod
-    def _with_shared(launch):
-        fn, args, block, grid, shared = launch
-        return fn, args, block, grid, shared
-
     def run(self, ticks, stream=None):
         """Enqueue `ticks` rollout ticks (asynchronous)."""
-        if self.group_plans:
-            cur = torch.cuda.current_stream()
-            stagger_us = float(os.environ.get("WD_STAGGER_US", "0"))
-            for g, (plan, s) in enumerate(zip(self.group_plans, self.group_streams)):
-                s.wait_stream(cur)
-                if stagger_us > 0 and g > 0:  # start the groups out of phase
-                    fm = self.w.cuda_function_manager
-                    fm.initialize_functions(["wd_delay"])
-                    fm.get_function("wd_delay")(np.uint64(int(100 * stagger_us * g)), block=(1, 1, 1), grid=(1, 1),
-                                                stream=int(s.cuda_stream))
-                plan.run(ticks, int(s.cuda_stream))
-            for s in self.group_streams:
-                cur.wait_stream(s)
-            return
         self.plan.run(ticks, stream)
 
     def run_graph(self, ticks, ticks_per_graph=10, stream=None):
