@@ -47,8 +47,8 @@ PROFILE = [
      "  TC_STAMP(6);\n  int nid[KMAX], rank[KMAX];"),
     (TC, "  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest"),
     (TC, "  // C. peel the (at most K) ids off the mask in ascending order", "  TC_STAMP(8);\n  // C. peel"),
-    (TC, "  // ------------------------------------------------------------ gather (wave-private from here",
-     "  TC_STAMP(9);\n  // ---- gather (wave-private from here"),
+    (TC, "  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)",
+     "  TC_STAMP(9);\n  // ---- ids out"),
     (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
     (TC, "  __syncthreads();  // every runner's tag is counted\n", "  TC_STAMP(11);\n  __syncthreads();\n  TC_STAMP(12);\n"),
     (TC, "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n}\n", "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n  TC_STAMP(13); TC_STAMP_RT(15);\n}\n"),

@@ -163,12 +163,17 @@ __device__ __forceinline__ int tc_slab_sample(const float *row, int n, float u) 
     float p[TC_CH];
 #pragma unroll
     for (int i = 0; i < TC_CH; ++i) p[i] = row[i];  // immediate offsets; entries >= n are the next row's
-                                                    // (or, after the last row, table bytes): read, never used
+                                                    // (or, after the last row, table bytes): read, masked off below
+    // one compare + one shift-in-the-carry add per entry (m = 2m + [cum < u]); the entries past n are
+    // dropped with one AND at the end instead of a range check per entry
+    unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < TC_CH; ++i) {
       cum = (i == 0) ? p[0] : cum + p[i];
-      cnt += (i < n && cum < u) ? 1 : 0;
+      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(cum), "v"(u) : "vcc");
     }
+    // entry i sits on bit TC_CH-1-i
+    cnt = __popc(m & (((1u << n) - 1u) << (TC_CH - n)));
   } else {
     for (int i = 0; i < n; ++i) {
       cum = (i == 0) ? row[0] : cum + row[i];
@@ -804,10 +809,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   if (active && sg) tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid, rank);
   __builtin_amdgcn_s_setprio(0);
 
-  // ------------------------------------------------------------ gather (wave-private from here
-  // to the barrier: rows [64*wave, 64*wave + wrows) of the block belong to this wavefront's lanes)
-  const int wrow0 = wave * 64;
-  const int wrows = max(0, min(64, agents_here - wrow0));
+  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)
+  int wrow0 = wave * 64;
+  int wrows = max(0, min(64, agents_here - wrow0));
   {
     // neighbour ids: block-local 16-bit copies for the gather, and the [E, N, K] output through
     // the staging buffer (rows of K dwords, contiguous over the wavefront's agents)
@@ -834,6 +838,15 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
+  }
+  // ------------------------------------------------------------ gather: the block's rows are split
+  // evenly over its wavefronts (105 agents: 53 + 52 rows instead of 64 + 41: one chunk less on the
+  // longer side), so a wavefront also gathers rows whose neighbours another wavefront found
+  __syncthreads();
+  {
+    const int rpw = (agents_here + n_waves - 1) / n_waves;
+    wrow0 = wave * rpw;
+    wrows = max(0, min(rpw, agents_here - wrow0));
   }
   {
     // observation rows, R rows per chunk: work item = (row, neighbour slot) -> 7 values at
