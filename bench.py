@@ -247,7 +247,9 @@ def main():
         if engine.fused:
             # a fused tick kernel also reads every head's probabilities and reads+writes the RNG epoch
             bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
-        bytes_per_launch = bytes_per_env_step * E * engine.ticks_per_launch
+        # A launch that fuses T ticks (Cartpole, fixed policy) rewrites the SAME addresses every tick: only
+        # one tick's worth of bytes can reach memory, so that is what the roofline is priced on
+        bytes_per_launch = bytes_per_env_step * E
         kern_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they
@@ -259,10 +261,11 @@ def main():
                 from warp_drive_amd.managers import hip_driver
 
                 sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
-                rec = json.load(open(pmc)).get(engine.step_kernel_name, {})
-                if (args.workload == "tag_continuous" and rec.get("num_envs") == E
-                        and rec.get("full_obs") == bool(args.full_obs) and rec.get("hsaco_sha256") == sha):
-                    traffic = rec.get("hbm_bytes_per_launch")
+                recs = [r for r in json.load(open(pmc)).values()
+                        if r.get("kernel") == engine.step_kernel_name and r.get("num_envs") == E
+                        and r.get("full_obs") == bool(args.full_obs) and r.get("hsaco_sha256") == sha]
+                if args.workload == "tag_continuous" and recs:
+                    traffic = recs[0].get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

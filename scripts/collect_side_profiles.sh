@@ -25,5 +25,4 @@ run --full-obs --steps 300 --warmup 30
 run --workload tag_gridworld --steps 2000 --warmup 100
 run --workload tag_gridworld --num-envs 100000 --steps 1000 --warmup 100
 run --workload cartpole --steps 2000 --warmup 100
-run --workload cartpole --steps 400 --warmup 40 --ticks-per-launch 50
 cat $S
