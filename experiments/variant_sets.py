@@ -96,3 +96,24 @@ SETS["flags"] = {
     "O2": [(None, "flag", "-O2")],
     "sched_ilp": [(None, "flag", "-mllvm"), (None, "flag", "-amdgpu-schedule-metric-bias=0")],
 }
+
+
+# ---- round 2, second look at the phase priorities (product = 3, 2, 1, 0)
+def _prio2(p_head, p_a, p_bc, p_g):
+    return [
+        (TC, "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;", f"  __builtin_amdgcn_s_setprio({p_head});\n  TcIn in;"),
+        (TC, "  __builtin_amdgcn_s_setprio(2);\n  if (active && sg) tc_knn_registers", f"  __builtin_amdgcn_s_setprio({p_a});\n  if (active && sg) tc_knn_registers"),
+        (TC, "  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K", f"  __builtin_amdgcn_s_setprio({p_bc});\n  // B[k], k = 1..K"),
+        (TC, "nid, rank);\n  __builtin_amdgcn_s_setprio(1);", f"nid, rank);\n  __builtin_amdgcn_s_setprio({p_g});"),
+    ]
+
+
+SETS["prio2"] = {
+    "p3211": [],
+    "p3210": _prio2(3, 2, 1, 0),
+    "p3321": _prio2(3, 3, 2, 1),
+    "p3200": _prio2(3, 2, 0, 0),
+    "p3220": _prio2(3, 2, 2, 0),
+    "p2210": _prio2(2, 2, 1, 0),
+    "p3110": _prio2(3, 1, 1, 0),
+}

@@ -23,21 +23,22 @@
 //       move     float32 kinematics exactly as numpy evaluates them (numpy-exact cos/sin);
 //                post-move state staged in LDS (positions; 32-byte feature records);
 //       tags     every runner finds its nearest tagger; tag counts through LDS atomics (their
-//                block barrier is the one after the neighbour phase);
+//                block barrier is the one after the gather);
 //       search   per agent, in registers: (A) the K+1 smallest squared distances with a
 //                v_med3_f32 chain; (B) one 128-bit mask "d^2 <= the K-th" built with
 //                v_cmp + v_addc (ties at the float32-sqrt cut resolved exactly as the stable
 //                heapq.nsmallest does); (C) the <= K set bits peeled in id order and ranked by
 //                (sqrt(d^2), id) with pairwise compare-and-count;
-//       gather   each WAVEFRONT turns the rows of its own 64 agents into observation rows inside a
-//                private LDS staging buffer, a chunk of rows at a time, and streams every chunk out
-//                as one contiguous run of 16-byte stores (the [E, N, F] layout makes a replica's
-//                rows contiguous); no block barrier between search and gather, so a wavefront's
-//                stores overlap the other wavefronts' search.  nearest_neighbor_ids leaves through
-//                the same staging buffer;
+//       ids out  nearest_neighbor_ids leaves through the wavefront's staging buffer; 16-bit
+//                block-local copies stay in LDS for the gather; one block barrier;
+//       gather   the block's rows are split evenly over its wavefronts; each WAVEFRONT turns its rows
+//                into observation rows inside a private LDS staging buffer, a chunk of rows at a
+//                time, and streams every chunk out as one contiguous run of write-through 16-byte
+//                stores (the [E, N, F] layout makes a replica's rows contiguous);
 //       rewards  tag counts -> rewards in the CPU's add order, done flags;
 //       reset    (fused tick) finished replicas are restored in place from the registered
 //                `*_at_reset` copies.
+//     Wave priority falls with the phase (s_setprio 3, 2, 1), so the wavefronts of a SIMD finish together.
 //
 //   tc_generic_impl      any N <= 1024, any K, full observations (entry points
 //     HipTagContinuousStep / HipTagContinuousTick): K-pass selection per agent, observation
@@ -748,11 +749,11 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // All global loads go out before anything else: the table set-up below (a dependent global load +
   // barrier) then runs in their shadow.
   const int env0 = a.env_begin + blockIdx.x * epb;
-  // Wave priority falls with the phase (3: fetch .. tags, 2: search A, 1: search B/C, 0: gather ..
-  // end): a wavefront that is behind wins VALU arbitration over one that is ahead, so the
+  // Wave priority falls with the phase (3: fetch .. tags, 2: search A, 1: search B/C and everything
+  // after): a wavefront that is behind wins VALU arbitration over one that is ahead, so the
   // wavefronts of a SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
   // and leaves the last wavefront of every SIMD running alone, latency-bound (measured: 48.6 ->
-  // 44.4 us per tick).
+  // 44.4 us per tick; 3,2,1,1 is another 0.5 us ahead of 3,2,1,0).
   __builtin_amdgcn_s_setprio(3);
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
@@ -807,7 +808,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }
   __builtin_amdgcn_s_setprio(2);
   if (active && sg) tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid, rank);
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(1);
 
   // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)
   int wrow0 = wave * 64;
