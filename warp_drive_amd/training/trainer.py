@@ -176,11 +176,23 @@ class Trainer:
         self._b_idx = torch.zeros(1, dtype=torch.long, device=self.device)  # batch row of the current tick
         self._tick_graph = None
         self._want_graph = bool(tcfg.get("graph_rollout", False)) and self.engine.fused
+        # precision of the policy forward in the ROLLOUT (the update always runs in float32, as the
+        # reference): "float32" (default, reference semantics) or "bfloat16" (torch autocast: the MLP's
+        # GEMMs on the bf16 matrix cores; the sampler still reads float32 probabilities)
+        self._rollout_dtype = {"float32": None, "bfloat16": torch.bfloat16}[str(tcfg.get("rollout_dtype", "float32"))]
 
     # --------------------------------------------------------------------------- rollout
     def _inference_model(self, pol):
         m = self.models[pol]
         return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+
+    def _rollout_forward(self, pol, obs_p):
+        """policy forward of the rollout: probabilities per head, float32"""
+        if self._rollout_dtype is None:
+            return self._inference_model(pol)(obs_p)[0]
+        with torch.autocast("cuda", dtype=self._rollout_dtype):
+            probs, _ = self._inference_model(pol)(obs_p)
+        return [p.float() for p in probs]
 
     @torch.no_grad()
     def _tick(self):
@@ -193,7 +205,7 @@ class Trainer:
             ids = self.ids[pol]
             obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
             self.batch[pol]["obs"].index_copy_(0, b, obs_p.unsqueeze(0))
-            probs, _ = self._inference_model(pol)(obs_p)
+            probs = self._rollout_forward(pol, obs_p)
             for h, p in enumerate(probs):
                 if len(self.policies) == 1:
                     self.probs[h].copy_(p)
@@ -358,7 +370,7 @@ class Trainer:
         for pol in self.policies:
             ids = self.ids[pol]
             obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
-            probs, _ = self._inference_model(pol)(obs_p)
+            probs = self._rollout_forward(pol, obs_p)
             out[pol] = probs
             for h, p in enumerate(probs):
                 if len(self.policies) == 1:
