@@ -112,7 +112,6 @@ __device__ __forceinline__ size_t tc_align16(size_t v) { return (v + 15) & ~(siz
 
 // replica-independent tables, alive for the whole launch
 struct TcTables {
-  int *types;        // [N]
   int *tagger_ids;   // [N] ascending
   float *acc_tab, *turn_tab;  // action tables (n_acc, n_turn entries; capacity WD_TC_TAB each)
   int *wave_cnt;     // [16] taggers per wavefront (rank computation)
@@ -124,7 +123,6 @@ struct TcTables {
 __device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, int N) {
   TcTables t;
   size_t off = 0;
-  t.types = (int *)(p + off); off += 4 * (size_t)N;
   t.tagger_ids = (int *)(p + off); off += 4 * (size_t)N;
   t.acc_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
   t.turn_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
@@ -226,7 +224,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
   }
 }
 
-// ---- replica-independent tables: agent types, ascending tagger list, action tables.
+// ---- replica-independent tables: ascending tagger list, action tables.
 // Returns the number of taggers.  Ends WITHOUT a barrier: the caller's next barrier publishes them.
 __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs &a, int N, int n_acc, int n_turn,
                                                bool tab_in_lds) {
@@ -240,7 +238,6 @@ __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs 
   const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
   if (N <= T_) {  // usual case: one barrier
     const int ty = (tid < N) ? a.agent_types[tid] : 0;
-    if (tid < N) tb.types[tid] = ty;
     const unsigned long long m = __ballot(ty == 1);
     if (lane == 0) tb.wave_cnt[wave] = __popcll(m);
     __syncthreads();
@@ -255,7 +252,6 @@ __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs 
     for (int base = 0; base < N; base += T_) {
       const int i = base + tid;
       const int ty = (i < N) ? a.agent_types[i] : 0;
-      if (i < N) tb.types[i] = ty;
       const unsigned long long m = __ballot(ty == 1);
       if (lane == 0) tb.wave_cnt[wave] = __popcll(m);
       __syncthreads();

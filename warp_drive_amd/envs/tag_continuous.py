@@ -15,7 +15,6 @@ the two differ by one ulp for ~0.07 % of inputs and only matter for exact near-t
 The device kernel squares the same way, so host and device agree with each other.
 """
 import copy
-import os
 
 import numpy as np
 
@@ -324,7 +323,7 @@ class TagContinuous(CUDAEnvironmentContext):
             area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
         if fused:  # the work area doubles as the two probability slabs (global_load_lds targets)
             area = max(area, align16(4 * A * len(self.acceleration_actions)) + align16(4 * A * len(self.turn_actions)))
-        return align16(area) + 4 * 2 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16
+        return align16(area) + 4 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16   # + tagger list, action tables, per-replica scalars
 
     def _geometry(self):
         """(replicas per block, block, grid): whole replicas packed into blocks of at most 256 threads
@@ -333,9 +332,8 @@ class TagContinuous(CUDAEnvironmentContext):
         (tc_fast_impl relies on it).  Full observations prefer the largest such block: that phase is
         bound by the store path and 4-wave blocks keep twice the stores in flight
         (scripts/write_pattern_probe.py)."""
-        max_threads = int(os.environ.get("WD_TC_MAX_THREADS", "256"))  # override: geometry experiments
         return self.cuda_function_manager.packed_geometry(
-            self.num_agents, max_threads=max_threads, prefer_large=bool(self.use_full_observation))
+            self.num_agents, max_threads=256, prefer_large=bool(self.use_full_observation))
 
     def _range_args(self, env_range):
         """step-kernel arguments for replicas [begin, end): kNumEnvs carries `end`, kEnvBegin `begin`"""
