@@ -117,3 +117,14 @@ SETS["prio2"] = {
     "p2210": _prio2(2, 2, 1, 0),
     "p3110": _prio2(3, 1, 1, 0),
 }
+
+
+# ---- code size: the K-specialised entry points hold two copies of the fast path (K == KM folded / runtime K)
+SETS["codesize"] = {
+    "base": [],
+    "exact_only": [
+        (TC, "    else tc_fast_impl<KM, false, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \\\n", ""),
+        (TC, "    else tc_fast_impl<KM, true, false>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \\\n", ""),
+    ],
+    "Os": [(None, "flag", "-Os")],
+}
