@@ -169,6 +169,14 @@ def test_bench_shape_vs_oracle():
     _run_lockstep(dict(BENCH_CFG, episode_length=12), E=64, ticks=30, seed=77)
 
 
+def test_bench_shape_soak_vs_oracle():
+    """3 million observation rows at the BASELINE shape (5 x 100, K = 10), free-running through
+    episode ends and restarts, every tick compared with the oracle: state, rewards, done and
+    observations bit-exact (a mismatching row would have to be a verified <= 2 ulp near-tie; the
+    session total is printed at the end of the run)."""
+    _run_lockstep(dict(BENCH_CFG, episode_length=60), E=192, ticks=150, seed=2024)
+
+
 def test_bench_full_size_properties():
     """num_envs = 2000 (BASELINE config[2]): size-independent properties.
     Replicas receive identical actions in groups of 8 => identical outputs inside a group;
