@@ -128,3 +128,12 @@ SETS["codesize"] = {
     ],
     "Os": [(None, "flag", "-Os")],
 }
+
+
+SETS["flags2"] = {
+    "base": [],
+    "Os": [(None, "flag", "-Os")],
+    "Oz": [(None, "flag", "-Oz")],
+    "O2": [(None, "flag", "-O2")],
+    "unroll8": [(None, "flag", "-mllvm"), (None, "flag", "-unroll-threshold=800")],
+}

@@ -24,7 +24,9 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 # -ffp-contract=off + correctly rounded div/sqrt are part of the parity contract
 # (see csrc/kernels/wd_common.h); do not change them without re-running the parity suite.
 KERNEL_FLAGS = [
-    "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
+    # -Os: the rollout kernels are issue-bound straight-line code; the size-optimised schedule measured
+    # 1.4 % faster than -O3 on the TagContinuous tick (38.25 -> 37.7 us; -O2 equal to -O3, -Oz 7 % slower)
+    "--offload-arch=gfx950", "--genco", "-Os", "-std=c++17", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
     # the fused tick kernels restore registered arrays through the reset table's untyped 32-bit
     # pointers, which alias the typed kernel arguments: no type-based alias analysis
@@ -62,6 +64,7 @@ def build_runtime(force=False, verbose=False):
 
 def build_kernels(force=False, verbose=False, extra_flags=()):
     srcs = [os.path.join(KDIR, f) for f in sorted(os.listdir(KDIR)) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.abspath(__file__))  # the compiler flags live here
     if not force and _newer(HSACO, srcs):
         return HSACO
     cmd = [_hipcc(), *KERNEL_FLAGS, *extra_flags, os.path.join(KDIR, "wd_kernels.hip"), "-o", HSACO]
