@@ -11,6 +11,7 @@ for graph, dtype in ((False, "float32"), (True, "float32"), (False, "bfloat16"),
     for _ in range(3): tr._generate_rollout_batch()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
+    tr.train(1); torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.train(2)
     torch.cuda.synchronize()

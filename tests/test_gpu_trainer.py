@@ -158,3 +158,25 @@ def test_fetch_episode_states_matches_the_oracle(tmp_path):
     again = trainer.fetch_episode_states(["loc_x"], env_id=0)
     np.testing.assert_array_equal(again["loc_x"][0], states["loc_x"][0])
     trainer.graceful_close()
+
+
+def test_inference_forward_on_device():
+    """fused-epilogue rollout forward vs the training forward on the GPU, float32 and bf16"""
+    import numpy as np
+
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.training.models import FullyConnected
+
+    require_gpu()
+    torch.manual_seed(3)
+    model = FullyConnected(71, [21, 21], [256, 256]).cuda()
+    obs = torch.randn(64, 105, 71, device="cuda")
+    probs, vals = model(obs)
+    probs_i, vals_i = model.forward_inference(obs)
+    for a, b in zip(probs, probs_i):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(vals.detach().cpu().numpy(), vals_i.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    probs_b, _ = model.forward_inference(obs, dtype=torch.bfloat16)
+    for a, b in zip(probs, probs_b):
+        assert b.dtype == torch.float32 and float((a.detach() - b).abs().max()) < 2e-2
+        np.testing.assert_allclose(b.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)

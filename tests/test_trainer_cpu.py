@@ -59,6 +59,20 @@ def test_objectives_and_model():
     assert ParamScheduler(0.3).get_param_value(7) == 0.3
 
 
+def test_inference_forward_equals_training_forward():
+    """the rollout's forward (fused epilogues, one GEMM for all heads) computes what forward() computes"""
+    torch.manual_seed(1)
+    model = FullyConnected(13, [4, 6, 3], [32, 16])
+    obs = torch.randn(5, 7, 13)
+    probs, vals = model(obs)
+    probs_i, vals_i = model.forward_inference(obs)
+    assert [tuple(p.shape) for p in probs_i] == [(5, 7, 4), (5, 7, 6), (5, 7, 3)] and tuple(vals_i.shape) == (5, 7)
+    for a, b in zip(probs, probs_i):
+        np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(vals.detach().numpy(), vals_i.numpy(), rtol=1e-5, atol=1e-6)
+    assert not any(p.requires_grad for p in probs_i)
+
+
 def test_config_merge_and_yaml_files():
     import yaml
 

@@ -177,8 +177,8 @@ class Trainer:
         self._tick_graph = None
         self._want_graph = bool(tcfg.get("graph_rollout", False)) and self.engine.fused
         # precision of the policy forward in the ROLLOUT (the update always runs in float32, as the
-        # reference): "float32" (default, reference semantics) or "bfloat16" (torch autocast: the MLP's
-        # GEMMs on the bf16 matrix cores; the sampler still reads float32 probabilities)
+        # reference): "float32" (default, reference semantics) or "bfloat16" (the MLP's GEMMs on the
+        # bf16 matrix cores; the sampler still reads float32 probabilities)
         self._rollout_dtype = {"float32": None, "bfloat16": torch.bfloat16}[str(tcfg.get("rollout_dtype", "float32"))]
 
     # --------------------------------------------------------------------------- rollout
@@ -188,11 +188,7 @@ class Trainer:
 
     def _rollout_forward(self, pol, obs_p):
         """policy forward of the rollout: probabilities per head, float32"""
-        if self._rollout_dtype is None:
-            return self._inference_model(pol)(obs_p)[0]
-        with torch.autocast("cuda", dtype=self._rollout_dtype):
-            probs, _ = self._inference_model(pol)(obs_p)
-        return [p.float() for p in probs]
+        return self._inference_model(pol).forward_inference(obs_p, dtype=self._rollout_dtype)[0]
 
     @torch.no_grad()
     def _tick(self):
