@@ -134,54 +134,6 @@ __device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, i
   return t;
 }
 
-// ---- fused tick: probability slab of ONE wavefront.  The rows of a wavefront's 64 agents are one
-// contiguous run of 64*n floats.  It goes global -> LDS directly (global_load_lds_dwordx4: per-lane
-// global address, LDS destination = wave-uniform base + lane*16; dword-aligned sources are enough),
-// 1 KiB per instruction, fully coalesced, no staging registers, asynchronous until the
-// `s_waitcnt vmcnt(0)` before the rows are read back (stride n dwords).  Producer and consumer are
-// the same wavefront: no block barrier.
-#define WD_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
-#define WD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
-__device__ __forceinline__ void tc_slab_fetch(float *dst, const float *__restrict__ src, int cnt, int lane) {
-  const int nvec = cnt >> 2;
-  const int nchunk = (nvec + 63) >> 6;  // wave-uniform
-  for (int c = 0; c < nchunk; ++c) {
-    const int q = c * 64 + lane;
-    if (q < nvec) __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * q), WD_LDS_PTR(dst + 256 * c), 16, 0, 0);
-  }
-  if (lane < (cnt & 3))  // the < 4 floats after the last vector
-    __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * nvec + lane), WD_LDS_PTR(dst + 4 * nvec), 4, 0, 0);
-}
-
-// inverse CDF on a running float32 sum (random.cu:51-85): number of prefix sums < u, clamped
-constexpr int TC_CH = 24;  // rows up to this length are read back with all LDS loads in flight
-__device__ __forceinline__ int tc_slab_sample(const float *row, int n, float u) {
-  int cnt = 0;
-  float cum = 0.0f;
-  if (n <= TC_CH) {
-    float p[TC_CH];
-#pragma unroll
-    for (int i = 0; i < TC_CH; ++i) p[i] = row[i];  // immediate offsets; entries >= n are the next row's
-                                                    // (or, after the last row, table bytes): read, masked off below
-    // one compare + one shift-in-the-carry add per entry (m = 2m + [cum < u]); the entries past n are
-    // dropped with one AND at the end instead of a range check per entry
-    unsigned m = 0u;
-#pragma unroll
-    for (int i = 0; i < TC_CH; ++i) {
-      cum = (i == 0) ? p[0] : cum + p[i];
-      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(cum), "v"(u) : "vcc");
-    }
-    // entry i sits on bit TC_CH-1-i
-    cnt = __popc(m & (((1u << n) - 1u) << (TC_CH - n)));
-  } else {
-    for (int i = 0; i < n; ++i) {
-      cum = (i == 0) ? row[0] : cum + row[i];
-      cnt += (cum < u) ? 1 : 0;
-    }
-  }
-  return min(cnt, n - 1);
-}
-
 // every global input of one loop trip; issued together so the HBM latency is paid once
 struct TcIn {
   int sg, type;
@@ -218,8 +170,8 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
     const int rows_here = min(epb, a.E - env0) * N;
     const int r0 = (tid >> 6) * 64, lane = tid & 63;
     const int wrows = max(0, min(64, rows_here - r0));
-    tc_slab_fetch(slab_acc + (size_t)r0 * n_acc, fz.probs_acc + ((long)env0 * N + r0) * n_acc, wrows * n_acc, lane);
-    tc_slab_fetch(slab_turn + (size_t)r0 * n_turn, fz.probs_turn + ((long)env0 * N + r0) * n_turn, wrows * n_turn,
+    wd_slab_fetch(slab_acc + (size_t)r0 * n_acc, fz.probs_acc + ((long)env0 * N + r0) * n_acc, wrows * n_acc, lane);
+    wd_slab_fetch(slab_turn + (size_t)r0 * n_turn, fz.probs_turn + ((long)env0 * N + r0) * n_turn, wrows * n_turn,
                   lane);
   }
 }
@@ -282,8 +234,8 @@ __device__ __forceinline__ int2 tc_sample_heads(const TcFuse &fz, const TcIn &in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   if (active) {
-    sampled.x = tc_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
-    sampled.y = tc_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
+    sampled.x = wd_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
+    sampled.y = wd_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
     ((int2 *)fz.actions_out)[gi] = sampled;
   }
   return sampled;

@@ -94,3 +94,52 @@ __device__ __forceinline__ float wd_u01_open_closed(uint32_t bits) {
 // RNG state layout in HBM (uint32 words): [0]=seed lo, [1]=seed hi, [2]=n_threads,
 // [3]=reserved, [4 + tid] = per-thread epoch counter.
 #define WD_RNG_HEADER 4
+
+// ---------------------------------------------------------------------------------
+// Probability slab of ONE wavefront (the categorical sampler and the fused tick kernels).  The rows of a wavefront's 64 agents are one
+// contiguous run of 64*n floats.  It goes global -> LDS directly (global_load_lds_dwordx4: per-lane
+// global address, LDS destination = wave-uniform base + lane*16; dword-aligned sources are enough),
+// 1 KiB per instruction, fully coalesced, no staging registers, asynchronous until the
+// `s_waitcnt vmcnt(0)` before the rows are read back (stride n dwords).  Producer and consumer are
+// the same wavefront: no block barrier.
+#define WD_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define WD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+__device__ __forceinline__ void wd_slab_fetch(float *dst, const float *__restrict__ src, int cnt, int lane) {
+  const int nvec = cnt >> 2;
+  const int nchunk = (nvec + 63) >> 6;  // wave-uniform
+  for (int c = 0; c < nchunk; ++c) {
+    const int q = c * 64 + lane;
+    if (q < nvec) __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * q), WD_LDS_PTR(dst + 256 * c), 16, 0, 0);
+  }
+  if (lane < (cnt & 3))  // the < 4 floats after the last vector
+    __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * nvec + lane), WD_LDS_PTR(dst + 4 * nvec), 4, 0, 0);
+}
+
+// inverse CDF on a running float32 sum (random.cu:51-85): number of prefix sums < u, clamped
+constexpr int WD_SLAB_CH = 24;  // rows up to this length are read back with all LDS loads in flight
+__device__ __forceinline__ int wd_slab_sample(const float *row, int n, float u) {
+  int cnt = 0;
+  float cum = 0.0f;
+  if (n <= WD_SLAB_CH) {
+    float p[WD_SLAB_CH];
+#pragma unroll
+    for (int i = 0; i < WD_SLAB_CH; ++i) p[i] = row[i];  // immediate offsets; entries >= n are the next row's
+                                                    // (or, after the last row, table bytes): read, masked off below
+    // one compare + one shift-in-the-carry add per entry (m = 2m + [cum < u]); the entries past n are
+    // dropped with one AND at the end instead of a range check per entry
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < WD_SLAB_CH; ++i) {
+      cum = (i == 0) ? p[0] : cum + p[i];
+      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(cum), "v"(u) : "vcc");
+    }
+    // entry i sits on bit WD_SLAB_CH-1-i
+    cnt = __popc(m & (((1u << n) - 1u) << (WD_SLAB_CH - n)));
+  } else {
+    for (int i = 0; i < n; ++i) {
+      cum = (i == 0) ? row[0] : cum + row[i];
+      cnt += (cum < u) ? 1 : 0;
+    }
+  }
+  return min(cnt, n - 1);
+}

@@ -61,15 +61,58 @@ __global__ void sample_actions(uint32_t *rng_state, const float *__restrict__ di
   (void)cum_distr;
   const int rows_per_block = blockDim.x;
   const uint32_t seed_lo = rng_state[0], seed_hi = rng_state[1];
+  if (lds_stride == num_actions && (blockDim.x & 63) == 0 && use_argmax <= 0) {
+    // Unpadded rows (the host asks for them when num_actions is odd: a stride of n dwords is then
+    // conflict-free as it is): every wavefront moves the contiguous rows of its own 64 threads
+    // global -> LDS with global_load_lds (1 KiB per instruction, no staging registers, no index
+    // arithmetic) and samples them after its own vmcnt wait -- no block barrier at all.
+    const int wave0 = (int)threadIdx.x & ~63, lane = (int)threadIdx.x & 63;
+    for (long row0 = (long)blockIdx.x * rows_per_block; row0 < n_rows;
+         row0 += (long)gridDim.x * rows_per_block) {
+      const long wrow0 = row0 + wave0;
+      const int wrows = (int)max(0L, min(64L, (long)n_rows - wrow0));
+      float *slab = s_rows + (size_t)wave0 * num_actions;
+      wd_slab_fetch(slab, distr + wrow0 * num_actions, wrows * num_actions, lane);
+      const long row = wrow0 + lane;
+      uint32_t epoch = 0u;
+      wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
+      if (lane < wrows) {
+        epoch = rng_state[WD_RNG_HEADER + row];
+        rng_state[WD_RNG_HEADER + row] = epoch + 1u;
+        rnd = wd_philox4x32_10(wd_u4{(uint32_t)row, epoch, (uint32_t)stream_tag, 0u}, seed_lo, seed_hi);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < wrows)
+        action_indices[row * out_stride + out_offset] =
+            wd_slab_sample(slab + (size_t)lane * num_actions, num_actions, wd_u01_open_closed(rnd.x));
+      __builtin_amdgcn_wave_barrier();  // (the next trip's fetch overwrites the slab)
+    }
+    return;
+  }
   for (long row0 = (long)blockIdx.x * rows_per_block; row0 < n_rows;
        row0 += (long)gridDim.x * rows_per_block) {
     const int rows_here = min((long)rows_per_block, (long)n_rows - row0);
     const long base = row0 * num_actions;
     const int total = rows_here * num_actions;
-    // coalesced slab load -> LDS (row stride padded)
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int r = i / num_actions, c = i - r * num_actions;
-      s_rows[r * lds_stride + c] = distr[base + i];
+    // coalesced slab load -> LDS (row stride padded).  (row, column) of element i advance
+    // incrementally with the block stride: no integer division per element
+    {
+      const int step_r = (int)blockDim.x / num_actions, step_c = (int)blockDim.x - step_r * num_actions;
+      int r = (int)threadIdx.x / num_actions, c = (int)threadIdx.x - r * num_actions;
+      constexpr int U = 4;  // loads in flight per thread
+      for (int i0 = threadIdx.x; i0 < total; i0 += U * blockDim.x) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = distr[base + min(i0 + u * (int)blockDim.x, total - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i0 + u * (int)blockDim.x < total) s_rows[r * lds_stride + c] = v[u];
+          r += step_r;
+          c += step_c;
+          if (c >= num_actions) { c -= num_actions; ++r; }
+        }
+      }
     }
     __syncthreads();
     if ((int)threadIdx.x < rows_here) {

@@ -393,16 +393,17 @@ class HIPSampler(CUDASampler):
         rollout launch plan."""
         stride = int(n_actions) | 1  # odd row stride: conflict-free LDS reads
         rows = self.ROWS_PER_BLOCK
-        while rows > 8 and rows * stride * 4 > self.MAX_DYNAMIC_LDS:  # long rows: fewer rows per block
+        while rows > 8 and rows * stride * 4 + 128 > self.MAX_DYNAMIC_LDS:  # long rows: fewer rows per block
             rows //= 2
-        assert rows * stride * 4 <= self.MAX_DYNAMIC_LDS, (
+        assert rows * stride * 4 + 128 <= self.MAX_DYNAMIC_LDS, (
             f"sample_actions stages {rows} rows of {n_actions} probabilities in LDS: more than "
             f"{self.MAX_DYNAMIC_LDS // (8 * 4) - 1} actions per head are not supported")
         grid = max(1, min(8192, (int(n_rows) + rows - 1) // rows))
         args = (self._rng_state, distribution_ptr, action_ptr, drv.DevicePtr(0), np.int32(n_rows),
                 np.int32(n_actions), np.int32(use_argmax), np.int32(stride), tag, np.int32(out_stride),
                 np.int32(out_offset))
-        return self.sample_actions, args, (rows, 1, 1), (grid, 1), rows * stride * 4
+        # (+128 B: the unrolled read-back of a short row runs up to 24 entries past the row's start)
+        return self.sample_actions, args, (rows, 1, 1), (grid, 1), rows * stride * 4 + 128
 
     def sample(self, data_manager, distribution: torch.Tensor, action_name: str, **sample_params):
         assert self._random_initialized, "sample() requires the random seed initialized first, please call init_random()"
