@@ -137,3 +137,32 @@ SETS["flags2"] = {
     "O2": [(None, "flag", "-O2")],
     "unroll8": [(None, "flag", "-mllvm"), (None, "flag", "-unroll-threshold=800")],
 }
+
+
+# ---- full observations (generic kernel): cache policy of the seven 16-byte (dword-aligned) row stores
+_FO_OLD = "          for (int c = 0; c < 7; ++c) *(TcF4u *)(row + c * W) = TcF4u{v[c][0], v[c][1], v[c][2], v[c][3]};"
+
+
+def _fo(policy):
+    return [(TC, _FO_OLD,
+             "          for (int c = 0; c < 7; ++c) { typedef float v4f_ __attribute__((ext_vector_type(4))); "
+             "const v4f_ t_ = {v[c][0], v[c][1], v[c][2], v[c][3]}; "
+             'asm volatile("global_store_dwordx4 %0, %1, off ' + policy + '" :: "v"(row + c * W), "v"(t_) : "memory"); }')]
+
+
+SETS_RETIRED_fullobs_store = {"base": [], "sc1": _fo("sc1"), "nt": _fo("nt"), "sc0sc1": _fo("sc0 sc1")}
+
+
+# (after the groups were aligned to the 16-byte grid of memory)
+_FO2_OLD = "              *(float4 *)(row + c * W + s0) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);"
+
+
+def _fo2(policy):
+    return [(TC, _FO2_OLD,
+             "              { typedef float v4f_ __attribute__((ext_vector_type(4))); "
+             "const v4f_ t_ = {v[c][0], v[c][1], v[c][2], v[c][3]}; "
+             'asm volatile("global_store_dwordx4 %0, %1, off ' + policy + '" :: "v"(row + c * W + s0), "v"(t_) : "memory"); }')]
+
+
+SETS_RETIRED_fullobs_store2 = {"base": [], "sc1": _fo2("sc1"), "nt": _fo2("nt")}
+SETS_RETIRED_fullobs_cmp = {"old": [], "base": [], "nt": _fo2("nt")}  # "old" = round-1 slot-indexed quads (built by hand from git)

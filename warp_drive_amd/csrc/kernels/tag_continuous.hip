@@ -939,7 +939,6 @@ __device__ __forceinline__ void tc_knn_generic(const float2 *cxy, const int *csi
   }
 }
 
-struct __attribute__((packed, aligned(4))) TcF4u { float x, y, z, w; };  // 16-byte access, dword aligned
 
 template <bool FUSED>
 __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
@@ -1017,31 +1016,52 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
       const int Wd = max(W, 1);
       if (a.use_full_obs && (W & 3) == 0 && W > 0) {
         // Full observations: rows are 7 runs of W consecutive floats, and the phase is bound by the
-        // number of store instructions (612 MB per tick at N = 105).  One work item = (row, four
-        // consecutive slots): 28 values, seven 16-byte stores (dword-aligned addresses).
-        const int nq = W >> 2;
-        int q = tid % nq, mq = tid / nq, iq = mq % N;
-        const int sq = T_ % nq, smq = T_ / nq, siq = smq % N;
-        for (int t = tid; t < agents_here * nq; t += T_) {
+        // store path (612 MB per tick at N = 105).  One work item = (row, group of four consecutive
+        // slots): 28 values, seven 16-byte stores.  The groups follow the 16-byte grid of MEMORY, not
+        // the slot index: a row starts at a dword-aligned address (F is odd), so group g of a row whose
+        // start is `mis` dwords past a 16-byte boundary covers slots 4g - mis .. 4g - mis + 3 (W is a
+        // multiple of 4: the same shift aligns all seven runs).  Every full group is then ONE aligned
+        // 16-byte store per run; only the clipped groups at the two ends of a run use dword stores.
+        const int ng = (W >> 2) + 1;  // groups per row, the clipped ones included
+        int g = tid % ng, mq = tid / ng, iq = mq % N;
+        const int sg = T_ % ng, smq = T_ / ng, siq = smq % N;
+        for (int t = tid; t < agents_here * ng; t += T_) {
           const int ebase = mq - iq;
           const bool in_game = l.sig[mq] != 0;
           const TcFeat me = l.feat[mq];
+          float *const row = obs_blk + (long)mq * F;
+          const int mis = (int)(((size_t)row >> 2) & 3);
+          const int s0 = 4 * g - mis;  // first slot of the group (< 0 / > W - 4: clipped)
           float v[7][4];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            const int kcol = 4 * q + kk;
+            const int kcol = min(max(s0 + kk, 0), W - 1);
             const TcFeat nb = l.feat[ebase + kcol + (kcol >= iq ? 1 : 0)];
             float vals[7];
             tc_obs_values(vals, nb, me, in_game, true);  // type / still_in_game columns are always filled
 #pragma unroll
             for (int c = 0; c < 7; ++c) v[c][kk] = vals[c];
           }
-          float *row = obs_blk + (long)mq * F + 4 * q;
+          if (s0 >= 0 && s0 + 3 < W) {
 #pragma unroll
-          for (int c = 0; c < 7; ++c) *(TcF4u *)(row + c * W) = TcF4u{v[c][0], v[c][1], v[c][2], v[c][3]};
-          q += sq;
-          const int carry = (q >= nq) ? 1 : 0;
-          q -= carry ? nq : 0;
+            for (int c = 0; c < 7; ++c) {
+              // non-temporal: 612 MB per tick stream through; measured 192 us (plain) -> 160 us, the
+              // round-1 slot-indexed (dword-aligned) quads 178 us; write-through (sc1) 475 us here
+              typedef float v4f __attribute__((ext_vector_type(4)));
+              const v4f quad = {v[c][0], v[c][1], v[c][2], v[c][3]};
+              __builtin_nontemporal_store(quad, (v4f *)(row + c * W + s0));
+            }
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              if (s0 + kk >= 0 && s0 + kk < W) {
+#pragma unroll
+                for (int c = 0; c < 7; ++c) row[c * W + s0 + kk] = v[c][kk];
+              }
+          }
+          g += sg;
+          const int carry = (g >= ng) ? 1 : 0;
+          g -= carry ? ng : 0;
           mq += smq + carry;
           iq += siq + carry;
           iq -= (iq >= N) ? N : 0;
