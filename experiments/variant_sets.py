@@ -166,3 +166,15 @@ def _fo2(policy):
 
 SETS_RETIRED_fullobs_store2 = {"base": [], "sc1": _fo2("sc1"), "nt": _fo2("nt")}
 SETS_RETIRED_fullobs_cmp = {"old": [], "base": [], "nt": _fo2("nt")}  # "old" = round-1 slot-indexed quads (built by hand from git)
+
+
+# ---- flush policy of the fast path, re-checked on the round-2 final kernel (product: sc1)
+_WT_OLD = 'asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(val) : "memory")'
+
+
+def _wt(policy):
+    return [(TC, _WT_OLD, 'asm volatile("global_store_dwordx4 %0, %1, off' + (" " + policy if policy else "") +
+             '" ::"v"(ptr), "v"(val) : "memory")')]
+
+
+SETS["flush_policy2"] = {"sc1": [], "plain": _wt(""), "nt": _wt("nt"), "sc0sc1": _wt("sc0 sc1"), "sc1nt": _wt("sc1 nt")}
