@@ -69,3 +69,46 @@ def test_train_two_ranks(tmp_path):
     assert recs[0][-1]["Iterations Completed"] == 2 and recs[1][-1]["Iterations Completed"] == 2
     # DDP keeps the replicas' models identical: rank 0 saves, and the ranks' losses differ (own replicas)
     assert any(f.endswith(".state_dict") for f in os.listdir(tmp_path))
+
+
+def _nccl_worker(port, out):
+    import torch
+    import torch.distributed as dist
+
+    from warp_drive_amd.training.models import FullyConnected
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    t = torch.arange(8, dtype=torch.float32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    model = torch.nn.parallel.DistributedDataParallel(FullyConnected(7, [3], [8]).cuda(), device_ids=[0])
+    probs, vals = model(torch.randn(4, 5, 7, device="cuda"))
+    (probs[0].sum() + vals.sum()).backward()  # bucketed gradient all-reduce through RCCL
+    ok = all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    open(out, "w").write(f"{dist.get_backend()} {int(ok)} {t.sum().item()}")
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_loads_and_reduces(tmp_path):
+    """backend "nccl" IS RCCL on ROCm: one rank on the one GPU of this box initialises it, runs an
+    all-reduce, a barrier and a DistributedDataParallel backward (the collectives bench.py and the trainer
+    use at N > 1).  Run in a child process so that the process group does not outlive the test."""
+    import multiprocessing as mp
+    import socket
+
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "nccl.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_worker, args=(port, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, f"RCCL worker exit code {p.exitcode}"
+    backend, ok, total = open(out).read().split()
+    assert backend == "nccl" and ok == "1" and float(total) == 28.0
