@@ -178,3 +178,6 @@ def _wt(policy):
 
 
 SETS["flush_policy2"] = {"sc1": [], "plain": _wt(""), "nt": _wt("nt"), "sc0sc1": _wt("sc0 sc1"), "sc1nt": _wt("sc1 nt")}
+
+
+SETS["prebuilt_pad"] = {"pad": [], "b3": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only

@@ -407,7 +407,6 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
   const float INF = __builtin_inff();
   // candidates are streamed four at a time, the next four positions being read from LDS while the
   // current four are processed (the search is latency-bound otherwise: one LDS round trip per group)
-  const int jclamp = max((N - 4) & ~1, 0);
 
   // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
   //    agents out of the game contribute +inf): B[k] = med3(B[k-1], B[k], d2), one op per slot,
@@ -425,7 +424,7 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
     TcP4 nxt = tc_load4(cxy, 0);
     for (int g = 0; g < ng; ++g) {
       const TcP4 cur = nxt;
-      nxt = tc_load4(cxy, min(4 * g + 4, jclamp));
+      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;
@@ -487,24 +486,61 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
     WD_TC_PUSH(m, d_[0], T2hi, "le"); WD_TC_PUSH(m, d_[1], T2hi, "le");         \
     WD_TC_PUSH(m, d_[2], T2hi, "le"); WD_TC_PUSH(m, d_[3], T2hi, "le");         \
   } while (0)
-    TcP4 ga = tc_load4(cxy, 0), gb;
+    int w_first = 0;  // words already done by the interleaved loop below
+    if (N >= 96) {
+      // three full words at once: three INDEPENDENT compare / carry chains interleaved, so that one
+      // chain's carry latency is covered by the other two (a single chain issues a dependent pair
+      // per candidate)
+      unsigned m3[3] = {0u, 0u, 0u};
+#define WD_TC_PUSH12(g0, g1, g2)                                                  \
+  do {                                                                            \
+    float e_[3][4];                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                               \
+      const float ax = xi - (g0).p[u].x, ay = yi - (g0).p[u].y;                   \
+      const float bx = xi - (g1).p[u].x, by = yi - (g1).p[u].y;                   \
+      const float cx = xi - (g2).p[u].x, cy = yi - (g2).p[u].y;                   \
+      e_[0][u] = ax * ax + ay * ay; e_[1][u] = bx * bx + by * by; e_[2][u] = cx * cx + cy * cy; \
+    }                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                               \
+      WD_TC_PUSH(m3[0], e_[0][u], T2hi, "le");                                    \
+      WD_TC_PUSH(m3[1], e_[1][u], T2hi, "le");                                    \
+      WD_TC_PUSH(m3[2], e_[2][u], T2hi, "le");                                    \
+    }                                                                             \
+  } while (0)
+      TcP4 a0 = tc_load4(cxy, 0), a1 = tc_load4(cxy, 32), a2 = tc_load4(cxy, 64), b0, b1, b2;
+      for (int b = 0; b < 32; b += 8) {
+        b0 = tc_load4(cxy, b + 4); b1 = tc_load4(cxy, b + 36); b2 = tc_load4(cxy, b + 68);
+        WD_TC_PUSH12(a0, a1, a2);
+        a0 = tc_load4(cxy, b + 8); a1 = tc_load4(cxy, b + 40); a2 = tc_load4(cxy, b + 72);
+        WD_TC_PUSH12(b0, b1, b2);
+      }
+#undef WD_TC_PUSH12
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
+        sel[w] = __brev(m3[w]) & ~self_bit;
+        n_upto += __popc(sel[w]);
+      }
+      w_first = 3;
+    }
+    TcP4 ga = tc_load4(cxy, 32 * w_first), gb;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int j0 = 32 * w;
-      if (j0 < N) {  // wave-uniform
+      if (w >= w_first && j0 < N) {  // wave-uniform
         const int nb = min(32, N - j0);
         unsigned mu = 0u;
         int b = 0;
         // two groups of four per trip, ping-pong: the loads of one group are in flight while the
         // other is processed, and no register is copied
         for (; b + 8 <= nb; b += 8) {
-          gb = tc_load4(cxy, min(j0 + b + 4, jclamp));
+          gb = tc_load4(cxy, j0 + b + 4);
           WD_TC_PUSH4(mu, ga);
-          ga = tc_load4(cxy, min(j0 + b + 8, jclamp));
+          ga = tc_load4(cxy, j0 + b + 8);  // (at most 8 entries past the last candidate: padding)
           WD_TC_PUSH4(mu, gb);
         }
         if (b + 4 <= nb) {
-          gb = tc_load4(cxy, min(j0 + b + 4, jclamp));
+          gb = tc_load4(cxy, j0 + b + 4);
           WD_TC_PUSH4(mu, ga);
           ga = gb;
           b += 4;
@@ -646,7 +682,8 @@ __device__ __forceinline__ int tc_stage_rows(int row_dwords) {
 // which are dead before the move phase writes it.
 struct TcFastLds {
   TcFeat *feat;          // [A] observation features
-  float2 *xy;            // [epb][NP] positions after the move (x = +BIG for agents out of the game), NP = N rounded up to even
+  float2 *xy;            // [epb][NP] positions after the move (x = +BIG for agents out of the game); NP = N rounded up
+                         // to a multiple of 4, plus 8 entries of padding that the search's prefetches may read
   int *sig;              // [A] still_in_the_game before this tick's tagging
   int *tagcnt;           // [A] tags credited to a tagger this tick
   unsigned short *ids;   // [A][K] block-local neighbour indices (0xffff = none)
@@ -662,7 +699,7 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   const int F = 7 * K + 1;
   size_t off = 0;
   l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
-  l.xy = (float2 *)(p0 + off); off += 8 * (size_t)epb * ((N + 1) & ~1);  // even stride per replica
+  l.xy = (float2 *)(p0 + off); off += 8 * (size_t)epb * (((N + 3) & ~3) + 8);  // see TcFastLds::xy
   l.sig = (int *)(p0 + off); off += 4 * A;
   l.tagcnt = (int *)(p0 + off); off += 4 * A;
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
@@ -690,7 +727,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   float *const stage = l.stage + (size_t)wave * l.stage_dwords;
   const int el = tid / N, ag = tid - el * N;
   const float invK = 1.0f / (float)K, invN = 1.0f / (float)N;
-  const int NP = (N + 1) & ~1;  // stride of a replica's positions in LDS (16-byte aligned pairs)
+  const int NP = ((N + 3) & ~3) + 8;  // stride of a replica's positions in LDS (16-byte aligned pairs + padding)
 
   // ONE trip per block (the host launches ceil(replicas / epb) blocks): every pointer argument is
   // used once and dies, which is what keeps the kernel inside 128 VGPRs / 104 SGPRs.

@@ -317,7 +317,7 @@ class TagContinuous(CUDAEnvironmentContext):
             n_waves = ((A if threads is None else threads) + 63) // 64
             stage_rows = max(1, min(64, self.STAGE_TARGET_BYTES // (4 * F)))
             stage_dwords = align16(4 * stage_rows * F) // 4 + 4
-            area = 32 * A + 8 * epb * ((N + 1) // 2 * 2) + 4 * A + 4 * A   # features, positions, 2 flag arrays
+            area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
             area = align16(area + 2 * A * K) + 4 * stage_dwords * n_waves  # 16-bit neighbour ids, staging
         else:
             area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
