@@ -400,6 +400,24 @@ __device__ __forceinline__ TcP4 tc_load4(const float2 *cxy, int j) {
   return r;
 }
 
+// rank of entry k in the reference's order (distance, then id): the entries are in ascending id
+// order already, so entry j > i goes first only when it is STRICTLY closer.  Counting (one compare
+// and two carry adds per pair) instead of a compare-exchange network: a 64-bit compare-exchange is
+// a compare plus four v_cndmask, the slowest instruction class on gfx950 when they come in runs.
+template <int KMAX>
+__device__ __forceinline__ void tc_rank_entries(const unsigned (&sb)[KMAX], int (&rank)[KMAX]) {
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+    for (int j = i + 1; j < KMAX; ++j) {
+      const int c = (sb[j] < sb[i]) ? 1 : 0;
+      rank[i] += c;
+      rank[j] -= c;
+    }
+}
+
 template <int KMAX>
 __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX],
                                                  int (&rank)[KMAX]) {
@@ -621,20 +639,7 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
     sb[k] = (jj[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
     nid[k] = jj[k];
   }
-  // rank of entry k in the reference's order (distance, then id): the entries are in ascending id
-  // order already, so entry j > i goes first only when it is STRICTLY closer.  Counting (one compare
-  // and two carry adds per pair) instead of a compare-exchange network: a 64-bit compare-exchange is
-  // a compare plus four v_cndmask, the slowest instruction class on gfx950 when they come in runs.
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) rank[k] = k;
-#pragma unroll
-  for (int i = 0; i < KMAX; ++i)
-#pragma unroll
-    for (int j = i + 1; j < KMAX; ++j) {
-      const int c = (sb[j] < sb[i]) ? 1 : 0;
-      rank[i] += c;
-      rank[j] -= c;
-    }
+  tc_rank_entries<KMAX>(sb, rank);
 }
 
 // Stream `n` dwords from a wavefront's staging buffer to global memory as one contiguous run.
