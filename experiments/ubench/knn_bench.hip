@@ -178,6 +178,25 @@ __global__ void __launch_bounds__(128) knn_bench(const float2 *pos, float *hints
     const unsigned long long t0 = __builtin_readcyclecounter();
     if (MODE == 0) {
       if (active) tc_knn_registers<KM>(xy, tid, N, K, nid, rank);
+    } else if (MODE == 2) {
+      bool exact = true;
+      int nid1[KM + 1], rank1[KM + 1];
+#pragma unroll
+      for (int k = 0; k <= KM; ++k) { nid1[k] = -1; rank1[k] = k; }
+      if (active) exact = tc_knn_packed<KM>(xy, tid, N, K, nid1, rank1);
+      if (!exact) {
+        tc_knn_registers<KM>(xy, tid, N, K, nid, rank);
+      } else {
+        // entries of rank < K -> slot `rank`
+#pragma unroll
+        for (int k = 0; k <= KM; ++k)
+          if (rank1[k] < K) {
+#pragma unroll
+            for (int q = 0; q < KM; ++q)
+              if (q == rank1[k]) { nid[q] = nid1[k]; rank[q] = q; }
+          }
+      }
+      slow_cnt += __popcll(__ballot(!exact));
     } else {
       const unsigned long long need = __ballot(active);
       uint2 *sbuf = sbuf_all + wave * 64 * K;
@@ -246,6 +265,19 @@ int main() {
     hipLaunchKernelGGL(knn_bench<1>, dim3(E), dim3(128), lds, 0, dpos, dhint, dout1, dcyc, dslow, N, K, L, jitter);
     CHECK(hipDeviceSynchronize());
     report("transposed, no hints");
+    {
+      std::vector<int> a(out_elems), b(out_elems);
+      CHECK(hipMemset(dout1, 0xff, 4 * out_elems));
+      hipLaunchKernelGGL(knn_bench<2>, dim3(E), dim3(128), lds, 0, dpos, dhint, dout1, dcyc, dslow, N, K, L, jitter);
+      hipLaunchKernelGGL(knn_bench<2>, dim3(E), dim3(128), lds, 0, dpos, dhint, dout1, dcyc, dslow, N, K, L, jitter);
+      CHECK(hipDeviceSynchronize());
+      report("one pass, packed keys");
+      CHECK(hipMemcpy(a.data(), dout0, 4 * out_elems, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(b.data(), dout1, 4 * out_elems, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < out_elems; ++i) bad += a[i] != b[i];
+      printf("packed keys: %zu of %zu entries differ\n", bad, out_elems);
+    }
     hipLaunchKernelGGL(knn_bench<1>, dim3(E), dim3(128), lds, 0, dpos, dhint, dout1, dcyc, dslow, N, K, L, jitter);
     CHECK(hipDeviceSynchronize());
     report("transposed, hints of the last run");

@@ -45,8 +45,10 @@ PROFILE = [
      "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
     (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX], rank[KMAX];",
      "  TC_STAMP(6);\n  int nid[KMAX], rank[KMAX];"),
-    (TC, "  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // B[k], k = 1..K are the K smallest"),
-    (TC, "  // C. peel the (at most K) ids off the mask in ascending order", "  TC_STAMP(8);\n  // C. peel"),
+    (TC, "  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry"),
+    # slot 8 is written only by wavefronts that enter the exact fallback (by whichever lanes do)
+    (TC, "#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }\n      tc_knn_registers<KMAX>",
+     "      if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();\n#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }\n      tc_knn_registers<KMAX>"),
     (TC, "  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)",
      "  TC_STAMP(9);\n  // ---- ids out"),
     (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
@@ -180,4 +182,21 @@ def _wt(policy):
 SETS["flush_policy2"] = {"sc1": [], "plain": _wt(""), "nt": _wt("nt"), "sc0sc1": _wt("sc0 sc1"), "sc1nt": _wt("sc1 nt")}
 
 
-SETS["prebuilt_pad"] = {"pad": [], "b3": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
+SETS["prebuilt_pad"] = {"b3": [], "pk2": [], "pk3": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
+
+
+# ---- one-pass packed-key search inside the tick: wave priority during the search, the exact
+# fallback compiled out, the old search (timing only)
+_PK_CALL = "    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank)) {"
+_PK_PRIO2 = "  __builtin_amdgcn_s_setprio(2);\n  if (active && sg) {"
+_PK_HALF = ("      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)\n"
+            "#pragma unroll\n      for (int u = 0; u < 4; ++u) {\n        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;\n"
+            "        const float d2 = dx * dx + dy * dy;\n        WD_TC_INSERT_KEY(d2, 4 * g + u);")
+SETS["pk_prio"] = {
+    "pk": [],
+    "pk_p1": [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(1);\n  if (active && sg) {")],
+    "pk_p3": [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
+    "pk_half": [(TC, _PK_HALF, _PK_HALF.replace("      nxt = tc_load4", "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);\n      nxt = tc_load4", 1))],
+    "pk_nofallback": [(TC, _PK_CALL, "    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank) && N < 0) {")],
+    "old": [(TC, _PK_CALL, "    if (true) {")],
+}

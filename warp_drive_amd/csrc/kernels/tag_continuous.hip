@@ -642,6 +642,138 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
   tc_rank_entries<KMAX>(sb, rank);
 }
 
+// ---- neighbour search in ONE pass over the candidates: the candidate's id rides in the low 7 bits
+// of its squared distance (key = d2 bits with the low 7 bits replaced by j; non-negative floats order
+// like unsigned integers) and a v_med3_u32 chain keeps the K+3 smallest keys, so the ids come out of
+// the chain itself -- no second pass that rebuilds every distance to form a mask, no peeling of the
+// mask.  The 7 dropped bits make the chain's order approximate (buckets of 128 ulps of d2); the
+// exact answer is rebuilt from it:
+//   * with b = bucket of the K-th other agent in chain order, a candidate whose bucket is >= b + 2 is
+//     more than 128 ulps of d2 farther than each of the first K, i.e. strictly farther in float32
+//     sqrt too: it cannot be among the K nearest.  The answer is a subset of {bucket <= b + 1};
+//   * the chain tracks K+2 other agents.  If the last of them has a bucket >= b + 2, the subset is
+//     inside the first K+1 tracked entries.  The exact keys (float32 distance, id) of the first K are
+//     rebuilt and ranked by counting; when the (K+1)-th sits in the uncertain buckets (~3e-4 per
+//     agent) it is ranked against them as well, and the entries of rank < K are the answer, in the
+//     reference's order;
+//   * otherwise (three candidates within 256 ulps of d2 at the cut: ~1e-7 per agent) the lane
+//     returns false and repeats the search with tc_knn_registers.  It has to be that rare: a
+//     wavefront that repeats the search does so alone, latency-bound, and the whole launch waits for
+//     it (with one look-ahead entry less, ~9 of 4000 wavefronts did, and the tick got 5 us longer).
+__device__ __forceinline__ unsigned tc_umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
+template <int KMAX>
+__device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX + 1],
+                                              int (&rank)[KMAX + 1]) {
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
+  constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
+  unsigned S[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
+#define WD_TC_INSERT_KEY(d2v, jv)                                                          \
+  do {                                                                                     \
+    const unsigned key_ = (__float_as_uint(d2v) & ~127u) | (unsigned)(jv);                 \
+    _Pragma("unroll") for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_); \
+    S[0] = min(S[0], key_);                                                                \
+  } while (0)
+  {
+    const int ng = N >> 2;
+    TcP4 nxt = tc_load4(cxy, 0);
+    for (int g = 0; g < ng; ++g) {
+      const TcP4 cur = nxt;
+      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;
+        const float d2 = dx * dx + dy * dy;
+        WD_TC_INSERT_KEY(d2, 4 * g + u);
+      }
+    }
+    for (int j = 4 * ng; j < N; ++j) {
+      const float2 pj = cxy[j];
+      const float dx = xi - pj.x, dy = yi - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      WD_TC_INSERT_KEY(d2, j);
+    }
+  }
+#undef WD_TC_INSERT_KEY
+  __builtin_amdgcn_s_setprio(1);
+  // drop the agent's own entry (d2 = 0 exactly: key == ag).  It is the first entry unless a twin with
+  // a lower id sits on the same spot.
+  unsigned o[KMAX + 2];
+  if (__ballot(S[0] != (unsigned)ag) == 0ull) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < KMAX + 2; ++k) o[k] = S[k + 1];
+  } else {
+    bool after = false;
+#pragma unroll
+    for (int k = 0; k < KMAX + 2; ++k) {
+      after = after || (S[k] == (unsigned)ag);
+      o[k] = after ? S[k + 1] : S[k];
+    }
+  }
+  // the K-th, (K+1)-th and (K+2)-th other agent in chain order
+  unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
+#pragma unroll
+  for (int k = 0; k < KMAX - 1; ++k) {
+    oK = (k == K - 1) ? o[k] : oK;
+    oExtra = (k == K - 1) ? o[k + 1] : oExtra;
+    oLook = (k == K - 1) ? o[k + 2] : oLook;
+  }
+  const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
+  const unsigned cut = (oK >> 7) + 2u;   // first bucket that is certainly outside
+  const bool exact = (oK >= INVALID) || ((oLook >> 7) >= cut);
+  // positions of the first K entries (all reads in flight together), exact keys, ranks
+  float2 pp[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const bool valid = (k < K) && (o[k] < INVALID);
+    nid[k] = valid ? (int)(o[k] & 127u) : -1;
+    pp[k] = cxy[valid ? nid[k] : ag];
+  }
+  unsigned long long key64[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const float dx = xi - pp[k].x, dy = yi - pp[k].y;
+    const unsigned sb = (nid[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
+    key64[k] = ((unsigned long long)sb << 32) | (unsigned)nid[k];
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+    for (int j = i + 1; j < KMAX; ++j) {
+      const int c = (key64[j] < key64[i]) ? 1 : 0;
+      rank[i] += c;
+      rank[j] -= c;
+    }
+  nid[KMAX] = -1;
+  rank[KMAX] = KMAX;
+  // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
+  if (oK < INVALID && oExtra < INVALID && (oExtra >> 7) < cut) {
+    const int idE = (int)(oExtra & 127u);
+    const float2 pe = cxy[idE];
+    const float dx = xi - pe.x, dy = yi - pe.y;
+    const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
+    int rE = K;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      const int c = (i < K && keyE < key64[i]) ? 1 : 0;
+      rank[i] += c;
+      rE -= c;
+    }
+    nid[KMAX] = idE;
+    rank[KMAX] = rE;
+  }
+  return exact;
+}
+
 // Stream `n` dwords from a wavefront's staging buffer to global memory as one contiguous run.
 // The producer placed dword i of the run at stage[mis + i], mis = (address of dst / 4) & 3, so the
 // 16-byte vectors of the run are 16-byte aligned in LDS and in memory alike; the <= 3 dwords before
@@ -793,11 +925,24 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     tagged = tc_find_tag(a, tb, l.xy + el * NP, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
 
   // ------------------------------------------------------------ search
-  int nid[KMAX], rank[KMAX];
+  int nid[KMAX + 1], rank[KMAX + 1];  // entry k is one of the K nearest iff rank[k] < K
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }
+  for (int k = 0; k <= KMAX; ++k) { nid[k] = -1; rank[k] = k; }
   __builtin_amdgcn_s_setprio(2);
-  if (active && sg) tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid, rank);
+  if (active && sg) {
+    // one pass with packed keys; a lane with three candidates inside 256 ulps at the cut (~1e-7 per
+    // agent) repeats the search with the two-pass one
+    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank)) {
+      int nid2[KMAX], rank2[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
+      tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid2, rank2);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = rank2[k]; }
+      nid[KMAX] = -1;
+      rank[KMAX] = KMAX;
+    }
+  }
   __builtin_amdgcn_s_setprio(1);
 
   // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)
@@ -812,7 +957,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     if (active) {
       const int ebase = el * N;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)  // (an entry's rank is < K unless it is one of the unused KMAX - K)
+      for (int k = 0; k <= KMAX; ++k)  // (K of the KMAX + 1 entries have a rank < K)
         if (rank[k] < K) l.ids[(size_t)li * K + rank[k]] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
     }
     for (int r0 = 0; r0 < wrows; r0 += rows_per_pass) {
@@ -820,7 +965,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       const int mis = (int)(((size_t)(nb_out + (long)r0 * K) >> 2) & 3);
       if (lane >= r0 && lane < r0 + rc) {
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k <= KMAX; ++k)
           if (rank[k] < K) istage[mis + (lane - r0) * K + rank[k]] = nid[k];
       }
       asm volatile("" ::: "memory");
