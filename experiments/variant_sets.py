@@ -182,7 +182,7 @@ def _wt(policy):
 SETS["flush_policy2"] = {"sc1": [], "plain": _wt(""), "nt": _wt("nt"), "sc0sc1": _wt("sc0 sc1"), "sc1nt": _wt("sc1 nt")}
 
 
-SETS["prebuilt_pad"] = {"b3": [], "pk2": [], "pk3": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
+SETS["prebuilt_pad"] = {"final": [], "apart": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
 
 
 # ---- one-pass packed-key search inside the tick: wave priority during the search, the exact
@@ -192,11 +192,23 @@ _PK_PRIO2 = "  __builtin_amdgcn_s_setprio(2);\n  if (active && sg) {"
 _PK_HALF = ("      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)\n"
             "#pragma unroll\n      for (int u = 0; u < 4; ++u) {\n        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;\n"
             "        const float d2 = dx * dx + dy * dy;\n        WD_TC_INSERT_KEY(d2, 4 * g + u);")
-SETS["pk_prio"] = {
+SETS_RETIRED_pk_prio = {
     "pk": [],
     "pk_p1": [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(1);\n  if (active && sg) {")],
     "pk_p3": [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
     "pk_half": [(TC, _PK_HALF, _PK_HALF.replace("      nxt = tc_load4", "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);\n      nxt = tc_load4", 1))],
-    "pk_nofallback": [(TC, _PK_CALL, "    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank) && N < 0) {")],
-    "old": [(TC, _PK_CALL, "    if (true) {")],
+    "pk_late1": [(TC, "  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry", "  // drop the agent's own entry")],
+}
+
+def _pk_drop(expr, to=1):
+    return [(TC, _PK_HALF, _PK_HALF.replace("      nxt = tc_load4", f"      if (g == ({expr})) __builtin_amdgcn_s_setprio({to});\n      nxt = tc_load4", 1))]
+
+
+SETS_RETIRED_pk_prio2 = {
+    "half": _pk_drop("ng >> 1"),
+    "quarter": _pk_drop("ng >> 2"),
+    "three_q": _pk_drop("(3 * ng) >> 2"),
+    "eighth": _pk_drop("ng >> 3"),
+    "p3_half": _pk_drop("ng >> 1") + [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
+    "half_to0": _pk_drop("ng >> 1", 0),
 }

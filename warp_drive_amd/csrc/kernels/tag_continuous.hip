@@ -651,6 +651,8 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
 //   * with b = bucket of the K-th other agent in chain order, a candidate whose bucket is >= b + 2 is
 //     more than 128 ulps of d2 farther than each of the first K, i.e. strictly farther in float32
 //     sqrt too: it cannot be among the K nearest.  The answer is a subset of {bucket <= b + 1};
+//   * nearly always the first K+1 entries are far enough apart for the chain order to be the exact
+//     order (see "apart" below) and nothing more is computed.  Otherwise:
 //   * the chain tracks K+2 other agents.  If the last of them has a bucket >= b + 2, the subset is
 //     inside the first K+1 tracked entries.  The exact keys (float32 distance, id) of the first K are
 //     rebuilt and ranked by counting; when the (K+1)-th sits in the uncertain buckets (~3e-4 per
@@ -686,6 +688,10 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
     TcP4 nxt = tc_load4(cxy, 0);
     for (int g = 0; g < ng; ++g) {
       const TcP4 cur = nxt;
+      // the second half of the chain runs at the priority of the phases after it (the caller entered
+      // at 2): measured 36.5 -> 35.6 us per tick; dropping after 1/8, 1/4 or 3/4 of the candidates, or
+      // not at all, is 0.1 .. 1 us slower
+      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);
       nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -717,59 +723,82 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
       o[k] = after ? S[k + 1] : S[k];
     }
   }
-  // the K-th, (K+1)-th and (K+2)-th other agent in chain order
-  unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
+  // Chain order IS the reference's order wherever neighbouring keys are >= 383 apart: then their
+  // buckets differ by two or more (the ids in the low bits move a key by < 128), so the squared
+  // distances differ by more than 128 ulps and the float32 distances strictly.  When that holds for
+  // the first K entries and the one after them (all but ~0.2 % of the agents) the low bits of the
+  // first K keys are the answer as they stand -- no positions re-read, no square roots, no ranking.
+  unsigned gap = 0xffffffffu;
 #pragma unroll
-  for (int k = 0; k < KMAX - 1; ++k) {
-    oK = (k == K - 1) ? o[k] : oK;
-    oExtra = (k == K - 1) ? o[k + 1] : oExtra;
-    oLook = (k == K - 1) ? o[k + 2] : oLook;
-  }
-  const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
-  const unsigned cut = (oK >> 7) + 2u;   // first bucket that is certainly outside
-  const bool exact = (oK >= INVALID) || ((oLook >> 7) >= cut);
-  // positions of the first K entries (all reads in flight together), exact keys, ranks
-  float2 pp[KMAX];
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) gap = min(gap, o[k + 1] - o[k]);  // (two slots without a candidate are 0 apart)
+  unsigned oKth = o[KMAX - 1];  // the K-th other agent in chain order
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const bool valid = (k < K) && (o[k] < INVALID);
-    nid[k] = valid ? (int)(o[k] & 127u) : -1;
-    pp[k] = cxy[valid ? nid[k] : ag];
-  }
-  unsigned long long key64[KMAX];
+  for (int k = 0; k < KMAX - 1; ++k) oKth = (k == K - 1) ? o[k] : oKth;
+  const bool apart = (gap >= 383u) && (oKth < 0x7f800000u);  // (and K others are in the game at all)
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    const float dx = xi - pp[k].x, dy = yi - pp[k].y;
-    const unsigned sb = (nid[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
-    key64[k] = ((unsigned long long)sb << 32) | (unsigned)nid[k];
+    nid[k] = (k < K) ? (int)(o[k] & 127u) : -1;
+    rank[k] = k;
   }
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) rank[k] = k;
-#pragma unroll
-  for (int i = 0; i < KMAX; ++i)
-#pragma unroll
-    for (int j = i + 1; j < KMAX; ++j) {
-      const int c = (key64[j] < key64[i]) ? 1 : 0;
-      rank[i] += c;
-      rank[j] -= c;
-    }
   nid[KMAX] = -1;
   rank[KMAX] = KMAX;
-  // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
-  if (oK < INVALID && oExtra < INVALID && (oExtra >> 7) < cut) {
-    const int idE = (int)(oExtra & 127u);
-    const float2 pe = cxy[idE];
-    const float dx = xi - pe.x, dy = yi - pe.y;
-    const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
-    int rE = K;
+  bool exact = true;
+  if (!apart) {
+    // the K-th, (K+1)-th and (K+2)-th other agent in chain order
+    unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      const int c = (i < K && keyE < key64[i]) ? 1 : 0;
-      rank[i] += c;
-      rE -= c;
+    for (int k = 0; k < KMAX - 1; ++k) {
+      oK = (k == K - 1) ? o[k] : oK;
+      oExtra = (k == K - 1) ? o[k + 1] : oExtra;
+      oLook = (k == K - 1) ? o[k + 2] : oLook;
     }
-    nid[KMAX] = idE;
-    rank[KMAX] = rE;
+    const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
+    const unsigned cut = (oK >> 7) + 2u;   // first bucket that is certainly outside
+    exact = (oK >= INVALID) || ((oLook >> 7) >= cut);
+    // positions of the first K entries (all reads in flight together), exact keys, ranks
+    float2 pp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const bool valid = (k < K) && (o[k] < INVALID);
+      nid[k] = valid ? (int)(o[k] & 127u) : -1;
+      pp[k] = cxy[valid ? nid[k] : ag];
+    }
+    unsigned long long key64[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float dx = xi - pp[k].x, dy = yi - pp[k].y;
+      const unsigned sb = (nid[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
+      key64[k] = ((unsigned long long)sb << 32) | (unsigned)nid[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+      for (int j = i + 1; j < KMAX; ++j) {
+        const int c = (key64[j] < key64[i]) ? 1 : 0;
+        rank[i] += c;
+        rank[j] -= c;
+      }
+    nid[KMAX] = -1;
+    rank[KMAX] = KMAX;
+    // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
+    if (oK < INVALID && oExtra < INVALID && (oExtra >> 7) < cut) {
+      const int idE = (int)(oExtra & 127u);
+      const float2 pe = cxy[idE];
+      const float dx = xi - pe.x, dy = yi - pe.y;
+      const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
+      int rE = K;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const int c = (i < K && keyE < key64[i]) ? 1 : 0;
+        rank[i] += c;
+        rE -= c;
+      }
+      nid[KMAX] = idE;
+      rank[KMAX] = rE;
+    }
   }
   return exact;
 }
@@ -871,9 +900,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // All global loads go out before anything else: the table set-up below (a dependent global load +
   // barrier) then runs in their shadow.
   const int env0 = a.env_begin + blockIdx.x * epb;
-  // Wave priority falls with the phase (3: fetch .. tags, 2: search A, 1: search B/C and everything
-  // after): a wavefront that is behind wins VALU arbitration over one that is ahead, so the
-  // wavefronts of a SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
+  // Wave priority falls with the phase (3: fetch .. tags, 2: first half of the search, 1: the rest
+  // of it and everything after): a wavefront that is behind wins VALU arbitration over one that is
+  // ahead, so the wavefronts of a SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
   // and leaves the last wavefront of every SIMD running alone, latency-bound (measured: 48.6 ->
   // 44.4 us per tick; 3,2,1,1 is another 0.5 us ahead of 3,2,1,0).
   __builtin_amdgcn_s_setprio(3);
