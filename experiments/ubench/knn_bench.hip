@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(128) knn_bench(const float2 *pos, float *hints
       int nid1[KM + 1], rank1[KM + 1];
 #pragma unroll
       for (int k = 0; k <= KM; ++k) { nid1[k] = -1; rank1[k] = k; }
-      if (active) exact = tc_knn_packed<KM>(xy, tid, N, K, nid1, rank1);
+      bool in_order = true;
+      if (active) exact = tc_knn_packed<KM>(xy, tid, N, K, nid1, rank1, in_order);
       if (!exact) {
         tc_knn_registers<KM>(xy, tid, N, K, nid, rank);
       } else {

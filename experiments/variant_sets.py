@@ -182,7 +182,7 @@ def _wt(policy):
 SETS["flush_policy2"] = {"sc1": [], "plain": _wt(""), "nt": _wt("nt"), "sc0sc1": _wt("sc0 sc1"), "sc1nt": _wt("sc1 nt")}
 
 
-SETS["prebuilt_pad"] = {"final": [], "apart": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
+SETS["prebuilt_pad"] = {"apart": [], "idsout": []}  # two hand-built code objects (build/variants/{prev,pad}.hsaco): bench only
 
 
 # ---- one-pass packed-key search inside the tick: wave priority during the search, the exact

@@ -669,9 +669,10 @@ __device__ __forceinline__ unsigned tc_umed3(unsigned a, unsigned b, unsigned c)
 }
 
 // nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
+// `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
 template <int KMAX>
 __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX + 1],
-                                              int (&rank)[KMAX + 1]) {
+                                              int (&rank)[KMAX + 1], bool &in_order) {
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
   unsigned S[L];
@@ -744,6 +745,7 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
   nid[KMAX] = -1;
   rank[KMAX] = KMAX;
   bool exact = true;
+  in_order = apart;
   if (!apart) {
     // the K-th, (K+1)-th and (K+2)-th other agent in chain order
     unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
@@ -957,11 +959,14 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   int nid[KMAX + 1], rank[KMAX + 1];  // entry k is one of the K nearest iff rank[k] < K
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) { nid[k] = -1; rank[k] = k; }
+  // in_order: slot k of the agent's row is entry k (true as well for agents that are not searched
+  // for: all their entries are "none")
+  bool in_order = true;
   __builtin_amdgcn_s_setprio(2);
   if (active && sg) {
     // one pass with packed keys; a lane with three candidates inside 256 ulps at the cut (~1e-7 per
     // agent) repeats the search with the two-pass one
-    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank)) {
+    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank, in_order)) {
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
@@ -970,6 +975,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = rank2[k]; }
       nid[KMAX] = -1;
       rank[KMAX] = KMAX;
+      in_order = false;
     }
   }
   __builtin_amdgcn_s_setprio(1);
@@ -979,23 +985,39 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   int wrows = max(0, min(64, agents_here - wrow0));
   {
     // neighbour ids: block-local 16-bit copies for the gather, and the [E, N, K] output through
-    // the staging buffer (rows of K dwords, contiguous over the wavefront's agents)
+    // the staging buffer (rows of K dwords, contiguous over the wavefront's agents).  Every lane
+    // writes entry k to slot k at fixed offsets; the few lanes whose entries are not in order
+    // (a near-tie, fewer than K agents in the game) then rewrite their rows by rank.
     int *const istage = (int *)stage;
     int *const nb_out = a.nearest_ids + ((long)env0 * N + wrow0) * K;
     const int rows_per_pass = max(1, min(64, (l.stage_dwords - 4) / K));
+    const int ebase = el * N;
+    const bool any_out_of_order = __ballot(!in_order) != 0ull;  // wave-uniform
+    const unsigned none_mask = (active && sg) ? 0u : 0xffffffffu;
     if (active) {
-      const int ebase = el * N;
+      unsigned short *const idrow = l.ids + (size_t)li * K;
 #pragma unroll
-      for (int k = 0; k <= KMAX; ++k)  // (K of the KMAX + 1 entries have a rank < K)
-        if (rank[k] < K) l.ids[(size_t)li * K + rank[k]] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
+      for (int k = 0; k < KMAX; ++k)  // (in-order rows hold K ids, or none at all: one mask per lane)
+        if (k < K) idrow[k] = (unsigned short)((unsigned)(ebase + nid[k]) | none_mask);
+      if (any_out_of_order && !in_order) {
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k)  // (K of the KMAX + 1 entries have a rank < K)
+          if (rank[k] < K) idrow[rank[k]] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
+      }
     }
     for (int r0 = 0; r0 < wrows; r0 += rows_per_pass) {
       const int rc = min(rows_per_pass, wrows - r0);
       const int mis = (int)(((size_t)(nb_out + (long)r0 * K) >> 2) & 3);
       if (lane >= r0 && lane < r0 + rc) {
+        int *const row = istage + mis + (lane - r0) * K;
 #pragma unroll
-        for (int k = 0; k <= KMAX; ++k)
-          if (rank[k] < K) istage[mis + (lane - r0) * K + rank[k]] = nid[k];
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) row[k] = nid[k];
+        if (any_out_of_order && !in_order) {
+#pragma unroll
+          for (int k = 0; k <= KMAX; ++k)
+            if (rank[k] < K) row[rank[k]] = nid[k];
+        }
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
