@@ -52,9 +52,9 @@ drv.memcpy_dtoh(raw, buf)
 drv.synchronize()
 st = raw.reshape(-1, 16).astype(np.int64)
 fell_back = st[:, 8] > 0
-print(f"wavefronts that entered the exact fallback search: {fell_back.sum()} of {(st[:, 13] > 0).sum()}")
+print(f"wavefronts with a lane outside the in-order exit of the search (exact ranking branch): {fell_back.sum()} of {(st[:, 13] > 0).sum()}")
 st[:, 8] = np.where(fell_back, st[:, 8], st[:, 7])
-names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "knn key chain", "(fallback entered)", "knn ranks (+fallback)",
+names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "knn key chain", "(ranking branch entered)", "knn ids / ranking branch",
          "ids flushed", "obs gathered+flushed", "barrier3", "rewards/end"]
 for wv, label in ((0, "wave 0 of each block (64 agents)"), (1, "wave 1 of each block (41 agents)")):
     s = st[wv::2]

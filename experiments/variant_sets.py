@@ -43,12 +43,11 @@ PROFILE = [
      "  TC_STAMP(2);\n  __syncthreads();\n  TC_STAMP(3);\n"),
     (TC, "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  __syncthreads();\n\n  // ------------------------------------------------------------ tags",
      "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
-    (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX], rank[KMAX];",
-     "  TC_STAMP(6);\n  int nid[KMAX], rank[KMAX];"),
+    (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX + 1], rank[KMAX + 1];",
+     "  TC_STAMP(6);\n  int nid[KMAX + 1], rank[KMAX + 1];"),
     (TC, "  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry"),
-    # slot 8 is written only by wavefronts that enter the exact fallback (by whichever lanes do)
-    (TC, "#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }\n      tc_knn_registers<KMAX>",
-     "      if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();\n#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { nid[k] = -1; rank[k] = k; }\n      tc_knn_registers<KMAX>"),
+    # slot 8 is written only by wavefronts in which some lane leaves the in-order exit of the one-pass search
+    (TC, "  in_order = apart;\n  if (!apart) {", "  in_order = apart;\n  if (!apart) {\n    if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();"),
     (TC, "  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)",
      "  TC_STAMP(9);\n  // ---- ids out"),
     (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
@@ -211,4 +210,20 @@ SETS_RETIRED_pk_prio2 = {
     "eighth": _pk_drop("ng >> 3"),
     "p3_half": _pk_drop("ng >> 1") + [(TC, _PK_PRIO2, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
     "half_to0": _pk_drop("ng >> 1", 0),
+}
+
+
+# ---- priorities again, after the one-pass search (product: 3 | 2 -> 1 at half of the chain | 1)
+_P_START = "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;"
+_P_SEARCH = "  __builtin_amdgcn_s_setprio(2);\n  if (active && sg) {"
+_P_HALF = "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);"
+_P_AFTER = "  __builtin_amdgcn_s_setprio(1);\n\n  // ------------------------------------------------------------ ids out"
+SETS["prio3"] = {
+    "base": [],
+    "start2": [(TC, _P_START, "  __builtin_amdgcn_s_setprio(2);\n  TcIn in;")],
+    "search3": [(TC, _P_SEARCH, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
+    "after0": [(TC, _P_AFTER, "  __builtin_amdgcn_s_setprio(0);\n\n  // ------------------------------------------------------------ ids out")],
+    "half0": [(TC, _P_HALF, "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);")],
+    "half0_after0": [(TC, _P_HALF, "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);"),
+                     (TC, _P_AFTER, "  __builtin_amdgcn_s_setprio(0);\n\n  // ------------------------------------------------------------ ids out")],
 }
