@@ -354,6 +354,73 @@ def test_exact_and_sqrt_ties_at_the_cut(K):
         assert ids[0, 0, 0] == 1
 
 
+@pytest.mark.parametrize("K", [3, 6])
+def test_candidates_a_few_ulps_apart_at_the_cut(K):
+    """The one-pass search orders candidates by squared distance with the low 7 bits dropped (buckets of
+    128 ulps) and must rebuild the reference's order exactly wherever that is too coarse.  One replica
+    per case: agent 0's K-th and (K+1)-th candidates sit `delta` ulps of squared distance apart --
+    inside one bucket, across a bucket boundary, just inside / outside the 383-apart rule -- with either
+    id the closer one; with `triple` a third candidate shares the zone (the two-pass search takes over).
+    Agents do not move.  Exact comparison with the oracle."""
+    from tests.hip_harness import OBS, pull, push_actions
+
+    n_runners = 10
+    cfg = dict(num_taggers=2, num_runners=n_runners, grid_length=20.0, episode_length=9, seed=1,
+               max_acceleration=0.1, min_acceleration=-0.1, num_acceleration_levels=4, num_turn_levels=4,
+               use_full_observation=False, num_other_agents_observed=K, tagging_distance=1e-5,
+               runner_exits_game_after_tagged=True)
+    deltas = [0, 1, 2, 3, 60, 127, 128, 129, 200, 255, 256, 257, 382, 383, 384, 500, 2000]
+    cases = [(d, swap, triple) for d in deltas for swap in (0, 1) for triple in (0, 1)]
+    E = len(cases)
+    w = _mk(cfg, E)
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    N = orc.N
+    f32 = np.float32
+    ulp4 = np.spacing(f32(4.0))
+    xs = np.zeros((E, N), f32)
+    ys = np.zeros((E, N), f32)
+    achieved = []
+    for e, (delta, swap, triple) in enumerate(cases):
+        # agent 0 at (8, 8); K-1 candidates closer than 2 on the +x ray; the pair at squared distance 4
+        # and 4 + delta ulps; the rest far away on a line
+        x = [8.0] + [8.0 + 0.3 * (j + 1) for j in range(K - 1)]
+        y = [8.0] * K
+        b = f32(np.sqrt(np.float64(delta) * np.float64(ulp4)))  # fl(b*b) ~ delta ulps of 4
+        pair = [(10.0, 8.0), (6.0, float(f32(8.0) + b))]        # squared distances 4 and ~4 + delta ulps
+        if swap:
+            pair = pair[::-1]
+        for px, py in pair:
+            x.append(px); y.append(py)
+        if triple:  # a third candidate 40 ulps above squared distance 4, below agent 0
+            b3 = f32(np.sqrt(40.0 * np.float64(ulp4)))
+            x.append(float(f32(8.0) + b3)); y.append(6.0)
+        k = len(x)
+        for j in range(k, N):
+            x.append(14.0 + 0.4 * (j - k)); y.append(15.0)
+        xs[e], ys[e] = np.array(x, f32), np.array(y, f32)
+        dx = (xs[e, 0] - xs[e]).astype(f32); dy = (ys[e, 0] - ys[e]).astype(f32)
+        d2 = ((dx * dx).astype(f32) + (dy * dy).astype(f32)).astype(f32)
+        achieved.append(int(abs(int(d2[K + 1].view(np.int32)) - int(d2[K].view(np.int32)))))
+    # the construction does produce the ulp distances it aims for (to within rounding of b*b)
+    for (delta, _, _), got in zip(cases, achieved):
+        assert abs(got - delta) <= max(2, delta // 50), (delta, got)
+    state = dict(loc_x=xs, loc_y=ys, speed=np.zeros((E, N), f32), direction=np.zeros((E, N), f32),
+                 acceleration=np.zeros((E, N), f32))
+    orc.set_state(**state)
+    _push_state(w, **state)
+    a0 = int(np.argmin(np.abs(orc.acceleration_actions)))
+    t0 = int(np.argmin(np.abs(orc.turn_actions)))
+    act = np.zeros((E, N, 2), dtype=np.int32)
+    act[..., 0], act[..., 1] = a0, t0
+    for t in range(2):
+        push_actions(w, act)
+        w.step_all_envs()
+        orc.step(act)
+        got, want = pull(w, OBS), orc.obs.astype(np.float32)
+        for e in range(E):
+            np.testing.assert_array_equal(got[e], want[e], err_msg=f"K={K} t={t} case (delta, swap, triple)={cases[e]}")
+
+
 @pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (525, 5, False), (1020, 3, False)])
 def test_many_agents_paths(n_runners, K, full_obs):
     """replicas larger than the bit-mask path: 129..512 agents use the LDS candidate lists of the
