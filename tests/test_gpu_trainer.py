@@ -108,6 +108,48 @@ def test_graph_and_eager_rollouts_agree(tmp_path):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_fused_policy_forward_in_the_rollout(tmp_path):
+    """The rollout with the policy forward as one kernel (training/policy_kernel.py, the default for
+    float32 rollouts of a supported shape) against the framework path: same observation rows in the
+    batch, probabilities equal to summation order, and -- the probabilities being that close -- the same
+    sampled actions except where a uniform draw falls within 1e-5 of a CDF step; the kernel keeps
+    following the weights through an update."""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.training.scripts.train import setup_trainer
+
+    require_gpu()
+    ov = {"trainer": {"num_envs": 40, "train_batch_size": 40 * 8, "num_episodes": 40, "seed": 11},
+          "env": {"num_runners": 30, "episode_length": 25, "num_other_agents_observed": 10},
+          "saving": {"metrics_log_freq": 100, "model_params_save_freq": 0}}
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        ov["trainer"]["fused_policy_forward"] = fused
+        tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"f{int(fused)}"), verbose=False)
+        assert all((f is not None) == fused for f in tr._fused_forward.values())
+        tr._b_idx.zero_()
+        tr._tick()  # one tick from identical states and identical initial weights
+        torch.cuda.synchronize()
+        res[fused] = dict(probs=[p.clone() for p in tr.probs], obs={p: tr.batch[p]["obs"][0].clone() for p in tr.policies},
+                          act=tr.actions.clone())
+        if fused:
+            tr.train(2)  # updates re-pack the weights: the kernel must agree with the updated network
+            flat = tr.obs.reshape(tr.num_envs, tr.w.n_agents, -1)
+            for pol in tr.policies:
+                want, _ = tr._inference_model(pol)(flat.index_select(1, tr.ids[pol]))
+                tr._fused_forward[pol](flat, tr._ids32[pol], tr.probs)
+                torch.cuda.synchronize()
+                for h, wnt in enumerate(want):
+                    got = tr.probs[h].index_select(1, tr.ids[pol])
+                    assert torch.allclose(got, wnt, rtol=2e-5, atol=2e-6), (pol, h)
+        tr.graceful_close()
+    for a, b in zip(res[True]["probs"], res[False]["probs"]):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6)
+    for pol in res[True]["obs"]:
+        assert torch.equal(res[True]["obs"][pol], res[False]["obs"][pol])
+    assert (res[True]["act"] != res[False]["act"]).float().mean().item() < 1e-3
+
+
 def test_fetch_episode_states_matches_the_oracle(tmp_path):
     """f4: Trainer.fetch_episode_states (reference trainer_base.py:689-792) -- one replica's states,
     actions and rewards for a whole episode, logged on the device by HIPLogController and pulled once.

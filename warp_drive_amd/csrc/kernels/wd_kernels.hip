@@ -8,3 +8,4 @@
 #include "tag_gridworld.hip"
 #include "tag_continuous.hip"
 #include "cartpole.hip"
+#include "policy_mlp.hip"

@@ -29,6 +29,7 @@ from warp_drive_amd.rollout import RolloutEngine
 from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
+from warp_drive_amd.training.policy_kernel import FusedPolicyForward
 from warp_drive_amd.utils.constants import Constants
 
 _ACTIONS, _REWARDS, _OBSERVATIONS = Constants.ACTIONS, Constants.REWARDS, Constants.OBSERVATIONS
@@ -180,6 +181,18 @@ class Trainer:
         # reference): "float32" (default, reference semantics) or "bfloat16" (the MLP's GEMMs on the
         # bf16 matrix cores; the sampler still reads float32 probabilities)
         self._rollout_dtype = {"float32": None, "bfloat16": torch.bfloat16}[str(tcfg.get("rollout_dtype", "float32"))]
+        # float32 rollouts of a supported policy shape run the forward as ONE kernel that reads the
+        # env's observation rows in place and writes the sampler's probability tensors and the batch
+        # copy of the rows (training/policy_kernel.py); `fused_policy_forward: False` keeps the
+        # framework path
+        self._fused_forward = {pol: None for pol in self.policies}
+        if self._rollout_dtype is None and bool(tcfg.get("fused_policy_forward", True)) and self.device.type == "cuda":
+            for pol in self.policies:
+                m = self._inference_model(pol)
+                obs_size = flattened_obs_size(env_wrapper.env.observation_space[self.policy_map[pol][0]])
+                if FusedPolicyForward.supports(m, obs_size) and self.obs.dtype == torch.float32:
+                    self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size)
+        self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
 
     # --------------------------------------------------------------------------- rollout
     def _inference_model(self, pol):
@@ -199,6 +212,10 @@ class Trainer:
         flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
         for pol in self.policies:
             ids = self.ids[pol]
+            if self._fused_forward[pol] is not None:
+                self._fused_forward[pol](flat_obs, self._ids32[pol], self.probs, obs_out=self.batch[pol]["obs"],
+                                         batch_row=b)
+                continue
             obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
             self.batch[pol]["obs"].index_copy_(0, b, obs_p.unsqueeze(0))
             probs = self._rollout_forward(pol, obs_p)
@@ -278,6 +295,8 @@ class Trainer:
             if pcfg["clip_grad_norm"]:
                 torch.nn.utils.clip_grad_norm_(self.models[pol].parameters(), pcfg["max_grad_norm"])
             self.optimizers[pol].step()
+            if self._fused_forward[pol] is not None:
+                self._fused_forward[pol].pack()  # the rollout kernel reads re-packed weights
             self.current_timestep[pol] += self.train_batch_size
             if log:
                 m["Current timestep"] = self.current_timestep[pol]
@@ -355,6 +374,8 @@ class Trainer:
                 self.current_timestep[pol] = int(stem.split("_")[-1])
             except ValueError:
                 pass
+            if getattr(self, "_fused_forward", {}).get(pol) is not None:
+                self._fused_forward[pol].pack()
 
     # ------------------------------------------------------------------- evaluation (f4)
     @torch.no_grad()
