@@ -48,17 +48,21 @@ __device__ __forceinline__ void mlp_fetch(float *buf, const float *src, int n_ti
 // acc[tn] += W_chunk[tn] . B   for one k-tile: 16 steps, B operand of step s = bfrag[s]
 template <int TN>
 __device__ __forceinline__ void mlp_ktile(mlp_v16 (&acc)[TN], const float *buf, const mlp_v16 &bfrag, int lane) {
+  // four output tiles at a time: 16 operand registers in flight instead of 4 * TN
+  constexpr int G = TN < 4 ? TN : 4;
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    mlp_v4 a[TN];
+  for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) a[tn] = *(const mlp_v4 *)(buf + ((tn * 4 + s4) * 64 + lane) * 4);
+    for (int t0 = 0; t0 < TN; t0 += G) {
+      mlp_v4 a[G];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int t = 0; t < G; ++t) a[t] = *(const mlp_v4 *)(buf + (((t0 + t) * 4 + s4) * 64 + lane) * 4);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tn][e], bfrag[4 * s4 + e], acc[tn], 0, 0, 0);
-  }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+          acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], bfrag[4 * s4 + e], acc[t0 + t], 0, 0, 0);
+    }
 }
 
 // acc += bias (packed per lane half: [tile][h][16]), optional ReLU
