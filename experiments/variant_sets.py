@@ -227,3 +227,22 @@ SETS["prio3"] = {
     "half0_after0": [(TC, _P_HALF, "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);"),
                      (TC, _P_AFTER, "  __builtin_amdgcn_s_setprio(0);\n\n  // ------------------------------------------------------------ ids out")],
 }
+
+
+# ---- phase stamps of the fused policy forward (experiments/mlp_profile.py)
+MLP = "policy_mlp.hip"
+_MLP_DEFS = '''extern "C" { __device__ unsigned long long *mlp_prof_g = nullptr; }
+#define MLP_STAMP(k) do { if ((threadIdx.x & 63) == 0 && mlp_prof_g) mlp_prof_g[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+namespace {
+
+typedef float mlp_v16'''
+SETS["mlp_profile"] = {"mlp_prof": [
+    (MLP, "namespace {\n\ntypedef float mlp_v16", _MLP_DEFS),
+    (MLP, "  // first weight chunk, then this lane's part of its observation row", "  MLP_STAMP(0);\n  // first weight chunk, then"),
+    (MLP, "  // ---- layer 1: H1^T = relu(W1 . X^T + b1)", "  MLP_STAMP(1);\n  // ---- layer 1"),
+    (MLP, "  mlp_relu<TN1>(acc1);", "  MLP_STAMP(2);\n  mlp_relu<TN1>(acc1);"),
+    (MLP, "  mlp_relu<TN2>(acc2);", "  MLP_STAMP(3);\n  mlp_relu<TN2>(acc2);"),
+    (MLP, "  // ---- softmax per head over the rows of a column", "  MLP_STAMP(4);\n  // ---- softmax"),
+    (MLP, "  constexpr int TS = 65;  // tile stride", "  MLP_STAMP(5);\n  constexpr int TS = 65;  // tile stride"),
+    (MLP, "  if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;", "  if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;\n  MLP_STAMP(6);"),
+]}

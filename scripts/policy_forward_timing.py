@@ -54,9 +54,15 @@ for label, ids in (("runners (200 000 rows)", list(range(5, 105))), ("taggers (1
 
     t_f32 = timed(framework)
     t_bf16 = timed(lambda: framework(torch.bfloat16))
+    per_waves = {}
+    for wpb in (1, 2, 4):
+        fused.WAVES_PER_BLOCK = wpb
+        per_waves[wpb] = timed(lambda: fused(obs, ids_t, probs, obs_out=batch_obs, batch_row=row))
+    fused.WAVES_PER_BLOCK = FusedPolicyForward.WAVES_PER_BLOCK
     t_fused = timed(lambda: fused(obs, ids_t, probs, obs_out=batch_obs, batch_row=row))
     t_pack = timed(fused.pack, n=10)
     rows = E * len(ids)
     flops = 2.0 * rows * (F * 256 + 256 * 256 + 256 * 43)
     print(f"{label}: framework fp32 {t_f32:8.1f} us | framework bf16 GEMMs {t_bf16:8.1f} us | fused fp32 MFMA "
-          f"{t_fused:8.1f} us ({flops / t_fused / 1e6:.1f} TFLOP/s useful) | re-pack after a weight update {t_pack:.0f} us")
+          f"{t_fused:8.1f} us ({flops / t_fused / 1e6:.1f} TFLOP/s useful; wavefronts per block 1/2/4: "
+          f"{per_waves[1]:.0f}/{per_waves[2]:.0f}/{per_waves[4]:.0f} us) | re-pack after a weight update {t_pack:.0f} us")

@@ -35,39 +35,54 @@ typedef float mlp_v4u __attribute__((ext_vector_type(4), aligned(4)));  // dword
 // row inside a 32-row tile of accumulator register s, lane half h
 __device__ __forceinline__ int mlp_row(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-// one chunk of packed weights (n_tiles x 4 KB) global -> LDS, split over the block's four wavefronts
+// one chunk of packed weights (n_tiles x 4 KB) global -> LDS, split over the block's wavefronts (1, 2 or 4)
 __device__ __forceinline__ void mlp_fetch(float *buf, const float *src, int n_tiles, int wave, int lane) {
-  // 16-byte vectors: n_tiles * 256; each wavefront moves a quarter, 64 vectors per instruction
-  const int rounds = n_tiles;  // (n_tiles * 256 / 4) / 64
+  // 16-byte vectors: n_tiles * 256; each wavefront moves its share, 64 vectors per instruction
+  const int rounds = n_tiles * 4 / (int)(blockDim.x >> 6);
   for (int r = 0; r < rounds; ++r) {
     const int v0 = (wave * rounds + r) * 64;  // first vector of this instruction (wave-uniform)
     __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * (v0 + lane)), WD_LDS_PTR(buf + 4 * v0), 16, 0, 0);
   }
 }
 
-// acc[tn] += W_chunk[tn] . B   for one k-tile: 16 steps, B operand of step s = bfrag[s]
-template <int TN>
+// acc[tn] += W_chunk[tn] . B for steps [4 * S4_BEGIN, 4 * S4_END) of one k-tile (16 steps; B operand of
+// step s = bfrag[s])
+template <int TN, int S4_BEGIN, int S4_END>
 __device__ __forceinline__ void mlp_ktile(mlp_v16 (&acc)[TN], const float *buf, const mlp_v16 &bfrag, int lane) {
-  // four output tiles at a time: 16 operand registers in flight instead of 4 * TN
-  constexpr int G = TN < 4 ? TN : 4;
+  // operands of G output tiles x 4 steps per LDS read group; the reads of the next group are issued
+  // before the MFMAs of the current one (one wavefront per SIMD: nobody else covers the LDS latency)
+  constexpr int G = TN < 2 ? TN : 2;
+  constexpr int GPS = TN / G;                   // groups per four steps
+  constexpr int G0 = S4_BEGIN * GPS, G1 = S4_END * GPS;
+  mlp_v4 a[3][G];  // three groups in flight: the reads run two groups (16 MFMAs) ahead
+#define MLP_READ_GROUP(gi_)                                                                             \
+  {                                                                                                     \
+    const int r4 = (gi_) / GPS, r0 = ((gi_) % GPS) * G;                                                 \
+    _Pragma("unroll") for (int t = 0; t < G; ++t)                                                       \
+        a[(gi_) % 3][t] = *(const mlp_v4 *)(buf + (((r0 + t) * 4 + r4) * 64 + lane) * 4);              \
+  }
+  MLP_READ_GROUP(G0)
+  if (G0 + 1 < G1) MLP_READ_GROUP(G0 + 1)
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4)
+  for (int gi = G0; gi < G1; ++gi) {
+    const int s4 = gi / GPS, t0 = (gi % GPS) * G;
+    if (gi + 2 < G1) MLP_READ_GROUP(gi + 2)
+    // (the scheduler otherwise sinks the reads to just before their first use -- fewer live registers,
+    // and an LDS round trip of dead matrix-pipe time per group)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t0 = 0; t0 < TN; t0 += G) {
-      mlp_v4 a[G];
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int t = 0; t < G; ++t) a[t] = *(const mlp_v4 *)(buf + (((t0 + t) * 4 + s4) * 64 + lane) * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < G; ++t)
-          acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], bfrag[4 * s4 + e], acc[t0 + t], 0, 0, 0);
-    }
+      for (int t = 0; t < G; ++t)
+        acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gi % 3][t][e], bfrag[4 * s4 + e], acc[t0 + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef MLP_READ_GROUP
 }
 
-// acc += bias (packed per lane half: [tile][h][16]), optional ReLU
-template <int TN, bool RELU>
-__device__ __forceinline__ void mlp_bias(mlp_v16 (&acc)[TN], const float *bias_packed, int h) {
+// accumulators start from the bias (packed per lane half: [tile][h][16]) instead of zero
+template <int TN>
+__device__ __forceinline__ void mlp_init(mlp_v16 (&acc)[TN], const float *bias_packed, int h) {
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const mlp_v4 *bp = (const mlp_v4 *)(bias_packed + (tn * 2 + h) * 16);
@@ -75,18 +90,24 @@ __device__ __forceinline__ void mlp_bias(mlp_v16 (&acc)[TN], const float *bias_p
     for (int q = 0; q < 4; ++q) {
       const mlp_v4 b = bp[q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = acc[tn][4 * q + e] + b[e];
-        acc[tn][4 * q + e] = RELU ? fmaxf(v, 0.0f) : v;
-      }
+      for (int e = 0; e < 4; ++e) acc[tn][4 * q + e] = b[e];
     }
   }
+}
+
+template <int TN>
+__device__ __forceinline__ void mlp_relu(mlp_v16 (&acc)[TN]) {
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[tn][s] = fmaxf(acc[tn][s], 0.0f);
 }
 
 struct MlpArgs {
   const float *obs;       // [E * N, F] observation rows (the env's own array)
   int F, N;               // row length, agents per replica
-  const int *agent_ids;   // [n_pol] agents of this policy inside a replica
+  const int *agent_ids;   // [n_pol] agents of this policy inside a replica; null: the range id0 .. id0 + n_pol - 1
+  int id0;
   int n_pol, n_rows;      // n_rows = E * n_pol
   const float *w1, *b1, *w2, *b2, *w3, *b3;  // packed (see training/policy_kernel.py)
   int A0, A1;             // sizes of the softmax heads (A1 = 0: one head); the value is output row A0 + A1
@@ -103,11 +124,11 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
   constexpr int CHUNK = (TN1 > TN2 ? TN1 : TN2) * 1024;  // floats per LDS buffer
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
   float *const buf0 = lds, *const buf1 = lds + CHUNK;
-  const int g = (blockIdx.x * 4 + wave) * 32 + j;  // policy-local row of this lane's column
+  const int g = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + j;  // policy-local row of this lane's column
   const bool valid = g < p.n_rows;
   const int gc = valid ? g : p.n_rows - 1;
   const int env = gc / p.n_pol, a = gc - env * p.n_pol;
-  const long src_row = (long)env * p.N + p.agent_ids[a];
+  const long src_row = (long)env * p.N + (p.agent_ids ? p.agent_ids[a] : p.id0 + a);
 
   // first weight chunk, then this lane's part of its observation row: features
   // [32 kt + 16 h, 32 kt + 16 h + 16) of k-tile kt (zero past the end of the row)
@@ -142,115 +163,141 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
       }
   }
 
-  // chunk c of the stream lives in buf[c & 1]; while it is consumed the next one is fetched
+  // chunk c of the stream lives in buf[c & 1]; while it is consumed the next one is fetched.  The
+  // fetch instructions come AFTER the first quarter of the chunk's MFMAs: at a chunk boundary the
+  // matrix pipe has nothing queued, so whatever is issued before the first MFMA is dead time
+  // (stamped build: ~1 200 cycles per boundary with the fetch first, 19 boundaries per block).
   int c = 0;
-#define MLP_NEXT_CHUNK(next_src, next_tiles, have_next)                                  \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's part of chunk c */ \
-  __syncthreads(); /* everybody's part; and nobody reads the other buffer any more */    \
-  if (have_next) mlp_fetch((c & 1) ? buf0 : buf1, (next_src), (next_tiles), wave, lane); \
-  const float *const cur = (c & 1) ? buf1 : buf0;                                        \
-  ++c;
+#define MLP_CHUNK(TN, acc, bfrag, next_src, next_tiles, have_next)                          \
+  {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's part of chunk c */  \
+    __syncthreads(); /* everybody's part; and nobody reads the other buffer any more */     \
+    const float *const cur = (c & 1) ? buf1 : buf0;                                         \
+    mlp_ktile<TN, 0, 1>(acc, cur, bfrag, lane);                                             \
+    if (have_next) mlp_fetch((c & 1) ? buf0 : buf1, (next_src), (next_tiles), wave, lane);  \
+    mlp_ktile<TN, 1, 4>(acc, cur, bfrag, lane);                                             \
+    ++c;                                                                                    \
+  }
 
   // ---- layer 1: H1^T = relu(W1 . X^T + b1)
-  mlp_v16 acc1[TN1];
-#pragma unroll
-  for (int tn = 0; tn < TN1; ++tn)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc1[tn][s] = 0.0f;
+  // (every layer's accumulators start from its bias; the loads are issued a layer ahead so that
+  // nobody waits for them -- one wavefront per SIMD has nothing else to run meanwhile)
+  mlp_v16 acc1[TN1], acc2[TN2], acc3[TN3];
+  mlp_init<TN1>(acc1, p.b1, h);
+  mlp_init<TN2>(acc2, p.b2, h);
 #pragma unroll
   for (int kt = 0; kt < KT1; ++kt) {
     const bool last = kt == KT1 - 1;
-    MLP_NEXT_CHUNK(last ? p.w2 : p.w1 + (size_t)(kt + 1) * TN1 * 1024, last ? TN2 : TN1, true)
-    mlp_ktile<TN1>(acc1, cur, feat[kt], lane);
+    MLP_CHUNK(TN1, acc1, feat[kt], last ? p.w2 : p.w1 + (size_t)(kt + 1) * TN1 * 1024, last ? TN2 : TN1, true)
   }
-  mlp_bias<TN1, true>(acc1, p.b1, h);
+  mlp_relu<TN1>(acc1);
 
   // ---- layer 2: H2^T = relu(W2 . H1^T + b2)
-  mlp_v16 acc2[TN2];
-#pragma unroll
-  for (int tn = 0; tn < TN2; ++tn)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc2[tn][s] = 0.0f;
+  mlp_init<TN3>(acc3, p.b3, h);
 #pragma unroll
   for (int kt = 0; kt < TN1; ++kt) {
     const bool last = kt == TN1 - 1;
-    MLP_NEXT_CHUNK(last ? p.w3 : p.w2 + (size_t)(kt + 1) * TN2 * 1024, last ? TN3 : TN2, true)
-    mlp_ktile<TN2>(acc2, cur, acc1[kt], lane);
+    MLP_CHUNK(TN2, acc2, acc1[kt], last ? p.w3 : p.w2 + (size_t)(kt + 1) * TN2 * 1024, last ? TN3 : TN2, true)
   }
-  mlp_bias<TN2, true>(acc2, p.b2, h);
+  mlp_relu<TN2>(acc2);
 
   // ---- output layer: logits^T (and the value) = W3 . H2^T + b3
-  mlp_v16 acc3[TN3];
-#pragma unroll
-  for (int tn = 0; tn < TN3; ++tn)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc3[tn][s] = 0.0f;
 #pragma unroll
   for (int kt = 0; kt < TN2; ++kt) {
     const bool last = kt == TN2 - 1;
-    MLP_NEXT_CHUNK(p.w3 + (size_t)(kt + 1) * TN3 * 1024, TN3, !last)
-    mlp_ktile<TN3>(acc3, cur, acc2[kt], lane);
+    MLP_CHUNK(TN3, acc3, acc2[kt], p.w3 + (size_t)(kt + 1) * TN3 * 1024, TN3, !last)
   }
-#undef MLP_NEXT_CHUNK
-  mlp_bias<TN3, false>(acc3, p.b3, h);
+#undef MLP_CHUNK
 
   // ---- softmax per head over the rows of a column: a lane holds half of the rows, its partner
-  // (lane ^ 32) the other half
+  // (lane ^ 32) the other half.  Straight-line code (selects, exp for every register): with one
+  // wavefront per SIMD every skipped-over branch costs as much as the work it skips.
   const int r1 = p.A0, r2 = p.A0 + p.A1;  // head 0: rows [0, r1), head 1: [r1, r2), value: row r2
-  float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+  const float NEG = -__builtin_inff();
+  float m0 = NEG, m1 = NEG;
 #pragma unroll
   for (int tn = 0; tn < TN3; ++tn)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int r = 32 * tn + mlp_row(s, h);
       const float x = acc3[tn][s];
-      if (r < r1) m0 = fmaxf(m0, x);
-      else if (r < r2) m1 = fmaxf(m1, x);
+      m0 = fmaxf(m0, (r < r1) ? x : NEG);
+      m1 = fmaxf(m1, (r >= r1 && r < r2) ? x : NEG);
     }
   m0 = fmaxf(m0, __shfl_xor(m0, 32));
   m1 = fmaxf(m1, __shfl_xor(m1, 32));
-  float z0 = 0.0f, z1 = 0.0f;
+  if (p.A1 == 0) m1 = 0.0f;  // (no second head: keep the arithmetic below finite)
+  float z0 = 0.0f, z1 = 0.0f, value = 0.0f;
 #pragma unroll
   for (int tn = 0; tn < TN3; ++tn)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int r = 32 * tn + mlp_row(s, h);
       const float x = acc3[tn][s];
-      if (r < r1) { const float e = expf(x - m0); acc3[tn][s] = e; z0 += e; }
-      else if (r < r2) { const float e = expf(x - m1); acc3[tn][s] = e; z1 += e; }
+      const bool in0 = r < r1, in1 = r >= r1 && r < r2;
+      value = (r == r2) ? x : value;
+      // (v_exp_f32: ~1 ulp of 2^t, t = (x - m) log2 e <= 0; rows outside the heads: anything finite)
+      const float e = __expf(fminf(x - (in0 ? m0 : m1), 0.0f));
+      z0 += in0 ? e : 0.0f;
+      z1 += in1 ? e : 0.0f;
+      acc3[tn][s] = e;
     }
   z0 += __shfl_xor(z0, 32);
   z1 += __shfl_xor(z1, 32);
-  if (!valid) return;
-  float *const o0 = p.probs0 + src_row * p.A0;
-  float *const o1 = p.A1 ? p.probs1 + src_row * p.A1 : nullptr;
+  const float inv0 = 1.0f / z0, inv1 = 1.0f / fmaxf(z1, 1.0e-30f);
+  // The probabilities leave through LDS so that every store instruction writes whole rows: a lane
+  // holds single elements of its agent's rows, and storing them directly is 64 separate 4-byte
+  // segments per instruction.  The tile [32 agents][64 rows (+1)] of a wavefront reuses the weight
+  // buffers once every wavefront is done with them (the host sizes the LDS for 4 tiles as well).
+  constexpr int TS = 65;  // tile stride (odd: conflict-free column writes)
+  __syncthreads();
+  float *const tile = lds + wave * (32 * TS + 32);
+  int *const tile_rows = (int *)(tile + 32 * TS);  // destination row of every agent of the tile (-1: none)
 #pragma unroll
   for (int tn = 0; tn < TN3; ++tn)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int r = 32 * tn + mlp_row(s, h);
-      const float x = acc3[tn][s];
-      if (r < r1) o0[r] = x / z0;
-      else if (r < r2) o1[r - r1] = x / z1;
-      else if (r == r2 && p.values) p.values[g] = x;
+      tile[j * TS + r] = acc3[tn][s] * ((r < r1) ? inv0 : inv1);
     }
+  if (h == 0) tile_rows[j] = valid ? (int)src_row : -1;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int head = 0; head < 2; ++head) {
+    const int A = head ? p.A1 : p.A0, off = head ? r1 : 0;
+    if (A == 0) break;
+    float *const out = head ? p.probs1 : p.probs0;
+    const int per_pass = 64 / A;                  // agents per store instruction (heads are <= 63 wide)
+    const int sub = (int)(((float)lane + 0.5f) / (float)A), col = lane - sub * A;  // lane -> (agent of the pass, column)
+    for (int a0 = 0; a0 < 32; a0 += per_pass) {
+      const int ag = a0 + sub;
+      if (sub < per_pass && ag < 32) {
+        const int row = tile_rows[ag];
+        if (row >= 0) out[(long)row * A + col] = tile[ag * TS + off + col];
+      }
+    }
+  }
+  // (the value is row r2: it sits in exactly one register of one lane half)
+  if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;
 }
 
 }  // namespace
 
 #define WD_MLP_PARAMS                                                                                 \
-  const float *obs, int F, int N, const int *agent_ids, int n_pol, int n_rows, const float *w1,       \
+  const float *obs, int F, int N, const int *agent_ids, int id0, int n_pol, int n_rows, const float *w1,       \
       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int A0,    \
       int A1, float *probs0, float *probs1, float *values, float *obs_out, const long long *batch_row
 #define WD_MLP_PACK()                                                                                 \
   MlpArgs p;                                                                                          \
-  p.obs = obs; p.F = F; p.N = N; p.agent_ids = agent_ids; p.n_pol = n_pol; p.n_rows = n_rows;         \
+  p.obs = obs; p.F = F; p.N = N; p.agent_ids = agent_ids; p.id0 = id0; p.n_pol = n_pol; p.n_rows = n_rows;         \
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.A0 = A0; p.A1 = A1;             \
   p.probs0 = probs0; p.probs1 = probs1; p.values = values; p.obs_out = obs_out; p.batch_row = batch_row;
 
 extern "C" {
 // HipPolicyMlp_<H1>x<H2>_k<KT1>: hidden widths H1, H2; observation rows of up to 32 * KT1 floats.
-// 256 threads per block (4 wavefronts x 32 rows), dynamic LDS = 2 * max(H1, H2) / 32 * 4096 bytes.
+// 64, 128 or 256 threads per block (wavefronts x 32 rows), dynamic LDS = max(2 * max(H1, H2) / 32 * 4096,
+// wavefronts * (32 * 65 + 32) * 4) bytes.
 #define WD_MLP_KERNEL(H1, H2, KT1)                                                                    \
   __global__ void __launch_bounds__(256, 1) HipPolicyMlp_##H1##x##H2##_k##KT1(WD_MLP_PARAMS) {        \
     extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \

@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 _WAVE_ROWS = 32          # observation rows (agents) per wavefront
-_BLOCK_ROWS = 4 * _WAVE_ROWS
 _OUT_TILES = 2           # output rows padded to 64: all head logits + the value
 
 
@@ -44,6 +43,7 @@ def _bias_indices(n_tiles):
 class FusedPolicyForward:
     HIDDEN = (64, 128, 256)
     MAX_OBS = 96
+    WAVES_PER_BLOCK = 4   # wavefronts that share one LDS copy of the streamed weights
 
     @classmethod
     def supports(cls, model, obs_size):
@@ -65,7 +65,8 @@ class FusedPolicyForward:
         name = f"HipPolicyMlp_{self.H}x{self.H}_k{self.kt1}"
         function_manager.initialize_functions([name])
         self.fn = function_manager.get_function(name)
-        self.lds_bytes = 2 * (self.H // 32) * 4096
+        # two weight buffers of one k-tile; reused at the end for one [32][65] output tile (+32 row ids) per wavefront
+        self.lds_bytes = max(2 * (self.H // 32) * 4096, 4 * (32 * 65 + 32) * 4)
         dev = next(model.parameters()).device
         tn = self.H // 32
         as_idx = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -75,6 +76,7 @@ class FusedPolicyForward:
         self._bidx = [as_idx(_bias_indices(tn)), as_idx(_bias_indices(tn)), as_idx(_bias_indices(_OUT_TILES))]
         self._pads = [(tn * 32, self.kt1 * 32), (tn * 32, tn * 32), (_OUT_TILES * 32, tn * 32)]
         self.packed = None
+        self._range_cache = {}
         self.pack()
 
     @torch.no_grad()
@@ -107,9 +109,18 @@ class FusedPolicyForward:
         n_rows = E * n_pol
         null = np.uint64(0)
         a1 = self.heads[1] if len(self.heads) > 1 else 0
-        args = [obs, np.int32(F), np.int32(N), agent_ids, np.int32(n_pol), np.int32(n_rows), *self.packed,
+        # a contiguous range of agents (the usual case) needs no id table in the kernel
+        key = int(agent_ids.data_ptr())
+        if self._range_cache.get("key") != key:
+            ids_host = agent_ids.cpu().numpy()
+            contiguous = bool((np.diff(ids_host) == 1).all()) if n_pol > 1 else True
+            self._range_cache = {"key": key, "id0": int(ids_host[0]), "contiguous": contiguous}
+        ids_arg = null if self._range_cache["contiguous"] else agent_ids
+        args = [obs, np.int32(F), np.int32(N), ids_arg, np.int32(self._range_cache["id0"]), np.int32(n_pol),
+                np.int32(n_rows), *self.packed,
                 np.int32(self.heads[0]), np.int32(a1), probs[0], probs[1] if a1 else null,
                 values if values is not None else null, obs_out if obs_out is not None else null,
                 batch_row if batch_row is not None else null]
-        grid = ((n_rows + _BLOCK_ROWS - 1) // _BLOCK_ROWS, 1)
-        self.fn(*args, block=(256, 1, 1), grid=grid, shared=self.lds_bytes)
+        block_rows = self.WAVES_PER_BLOCK * _WAVE_ROWS
+        grid = ((n_rows + block_rows - 1) // block_rows, 1)
+        self.fn(*args, block=(64 * self.WAVES_PER_BLOCK, 1, 1), grid=grid, shared=self.lds_bytes)
