@@ -246,3 +246,13 @@ SETS["mlp_profile"] = {"mlp_prof": [
     (MLP, "  constexpr int TS = 65;  // tile stride", "  MLP_STAMP(5);\n  constexpr int TS = 65;  // tile stride"),
     (MLP, "  if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;", "  if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;\n  MLP_STAMP(6);"),
 ]}
+
+
+# ---- optimisation level and priorities once more, on the round-2 final kernel (product: -Os; 3 | 2 -> 1 | 1)
+SETS["final_check"] = {
+    "base": [],
+    "O3": [(None, "flag", "-O3")],
+    "O2": [(None, "flag", "-O2")],
+    "p_half0_after0": [(TC, _P_HALF, "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);"),
+                       (TC, _P_AFTER, "  __builtin_amdgcn_s_setprio(0);\n\n  // ------------------------------------------------------------ ids out")],
+}
