@@ -218,7 +218,7 @@ _P_START = "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;"
 _P_SEARCH = "  __builtin_amdgcn_s_setprio(2);\n  if (active && sg) {"
 _P_HALF = "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);"
 _P_AFTER = "  __builtin_amdgcn_s_setprio(1);\n\n  // ------------------------------------------------------------ ids out"
-SETS["prio3"] = {
+SETS_RETIRED_prio3 = {
     "base": [],
     "start2": [(TC, _P_START, "  __builtin_amdgcn_s_setprio(2);\n  TcIn in;")],
     "search3": [(TC, _P_SEARCH, "  __builtin_amdgcn_s_setprio(3);\n  if (active && sg) {")],
@@ -249,7 +249,7 @@ SETS["mlp_profile"] = {"mlp_prof": [
 
 
 # ---- optimisation level and priorities once more, on the round-2 final kernel (product: -Os; 3 | 2 -> 1 | 1)
-SETS["final_check"] = {
+SETS_RETIRED_final_check = {
     "base": [],
     "O3": [(None, "flag", "-O3")],
     "O2": [(None, "flag", "-O2")],

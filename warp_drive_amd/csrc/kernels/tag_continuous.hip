@@ -38,7 +38,7 @@
 //       rewards  tag counts -> rewards in the CPU's add order, done flags;
 //       reset    (fused tick) finished replicas are restored in place from the registered
 //                `*_at_reset` copies.
-//     Wave priority falls with the phase (s_setprio 3, 2, 1), so the wavefronts of a SIMD finish together.
+//     Wave priority falls with the phase (s_setprio 3, 2, 0), so the wavefronts of a SIMD finish together.
 //
 //   tc_generic_impl      any N <= 1024, any K, full observations (entry points
 //     HipTagContinuousStep / HipTagContinuousTick): K-pass selection per agent, observation
@@ -689,10 +689,11 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
     TcP4 nxt = tc_load4(cxy, 0);
     for (int g = 0; g < ng; ++g) {
       const TcP4 cur = nxt;
-      // the second half of the chain runs at the priority of the phases after it (the caller entered
-      // at 2): measured 36.5 -> 35.6 us per tick; dropping after 1/8, 1/4 or 3/4 of the candidates, or
-      // not at all, is 0.1 .. 1 us slower
-      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(1);
+      // the second half of the chain runs at the lowest priority, like the phases after the search
+      // (the caller entered at 2): measured 36.5 -> 35.6 us per tick with 1 here, another 0.2 us with
+      // 0 here and after the search; dropping after 1/8, 1/4 or 3/4 of the candidates, or not at
+      // all, is 0.1 .. 1 us slower
+      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);
       nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -902,9 +903,10 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // All global loads go out before anything else: the table set-up below (a dependent global load +
   // barrier) then runs in their shadow.
   const int env0 = a.env_begin + blockIdx.x * epb;
-  // Wave priority falls with the phase (3: fetch .. tags, 2: first half of the search, 1: the rest
-  // of it and everything after): a wavefront that is behind wins VALU arbitration over one that is
-  // ahead, so the wavefronts of a SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
+  // Wave priority falls with the phase (3: fetch .. tags, 2: first half of the search, 0: the rest
+  // of it and everything after, with a short stretch at 1 where the ids come out of the keys): a
+  // wavefront that is behind wins VALU arbitration over one that is ahead, so the wavefronts of a
+  // SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
   // and leaves the last wavefront of every SIMD running alone, latency-bound (measured: 48.6 ->
   // 44.4 us per tick; 3,2,1,1 is another 0.5 us ahead of 3,2,1,0).
   __builtin_amdgcn_s_setprio(3);
@@ -978,7 +980,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       in_order = false;
     }
   }
-  __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(0);
 
   // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)
   int wrow0 = wave * 64;
