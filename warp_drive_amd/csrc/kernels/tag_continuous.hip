@@ -24,13 +24,16 @@
 //                post-move state staged in LDS (positions; 32-byte feature records);
 //       tags     every runner finds its nearest tagger; tag counts through LDS atomics (their
 //                block barrier is the one after the gather);
-//       search   per agent, in registers: (A) the K+1 smallest squared distances with a
-//                v_med3_f32 chain; (B) one 128-bit mask "d^2 <= the K-th" built with
-//                v_cmp + v_addc (ties at the float32-sqrt cut resolved exactly as the stable
-//                heapq.nsmallest does); (C) the <= K set bits peeled in id order and ranked by
-//                (sqrt(d^2), id) with pairwise compare-and-count;
-//       ids out  nearest_neighbor_ids leaves through the wavefront's staging buffer; 16-bit
-//                block-local copies stay in LDS for the gather; one block barrier;
+//       search   per agent, in registers, ONE pass over the candidates: the candidate id rides in
+//                the low 7 bits of the squared distance through a v_med3_u32 chain that keeps the
+//                K+3 smallest keys; where the first K+1 keys are far enough apart the chain order
+//                is the reference's order and the ids are read off the keys, otherwise the exact
+//                (sqrt(d^2), id) keys of the first K(+1) entries are ranked by pairwise
+//                compare-and-count; ~1e-7 of the agents repeat the search with the two-pass one
+//                (tc_knn_registers: exact K-th distance, compare-mask pass, id-ordered peeling);
+//       ids out  nearest_neighbor_ids leaves through the wavefront's staging buffer (entry k ->
+//                slot k; out-of-order lanes rewrite their rows by rank); 16-bit block-local copies
+//                stay in LDS for the gather; one block barrier;
 //       gather   the block's rows are split evenly over its wavefronts; each WAVEFRONT turns its rows
 //                into observation rows inside a private LDS staging buffer, a chunk of rows at a
 //                time, and streams every chunk out as one contiguous run of write-through 16-byte
