@@ -910,8 +910,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // of it and everything after, with a short stretch at 1 where the ids come out of the keys): a
   // wavefront that is behind wins VALU arbitration over one that is ahead, so the wavefronts of a
   // SIMD finish together.  The default oldest-first arbitration keeps leaders ahead
-  // and leaves the last wavefront of every SIMD running alone, latency-bound (measured: 48.6 ->
-  // 44.4 us per tick; 3,2,1,1 is another 0.5 us ahead of 3,2,1,0).
+  // and leaves the last wavefront of every SIMD running alone, latency-bound (measured with the
+  // two-pass search: 48.6 -> 44.4 us per tick; the schedule was re-tuned for the one-pass search,
+  // experiments/README.md).
   __builtin_amdgcn_s_setprio(3);
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
