@@ -25,7 +25,8 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 # (see csrc/kernels/wd_common.h); do not change them without re-running the parity suite.
 KERNEL_FLAGS = [
     # -Os: the rollout kernels are issue-bound straight-line code; the size-optimised schedule measured
-    # 1.4 % faster than -O3 on the TagContinuous tick (38.25 -> 37.7 us; -O2 equal to -O3, -Oz 7 % slower)
+    # 1.4 % faster than -O3 on the TagContinuous tick (38.25 -> 37.7 us; -O2 equal to -O3, -Oz 7 % slower;
+    # again on the round-2 final kernel: -Os 34.1, -O2 34.5, -O3 34.6 us)
     "--offload-arch=gfx950", "--genco", "-Os", "-std=c++17", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
     # the fused tick kernels restore registered arrays through the reset table's untyped 32-bit
