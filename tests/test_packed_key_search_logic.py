@@ -128,3 +128,33 @@ def test_pairs_a_few_ulps_apart_everywhere_in_the_list(swap):
                 continue
             assert got == _reference(x, y, np.ones(N, np.int32), 0, K), (pos, delta, swap)
     assert stats["fallback"] == 0  # a lone pair never needs the two-pass search
+
+
+def test_many_candidates_within_a_few_hundred_ulps():
+    """eight candidates whose squared distances to agent 0 lie within 600 ulps of each other, around
+    the cut: whenever the rule does not hand over to the two-pass search its answer must be exact"""
+    rng = np.random.default_rng(5)
+    K, N = 6, 16
+    ulp4 = np.spacing(f32(4.0))
+    answered = fell_back = 0
+    for trial in range(400):
+        n_close = int(rng.integers(2, 5))           # candidates well inside
+        m = np.sort(rng.integers(0, 600, size=8))    # ulps above squared distance 4
+        x = [8.0] + [8.0 + 0.25 * (j + 1) for j in range(n_close)]
+        y = [8.0] * (n_close + 1)
+        order = rng.permutation(8)                   # ids in random order relative to distance
+        for q in order:
+            b = f32(np.sqrt(np.float64(m[q]) * np.float64(ulp4)))
+            side = 10.0 if q % 2 else 6.0
+            x.append(side); y.append(float(f32(8.0) + b))
+        while len(x) < N:
+            x.append(14.0 + 0.5 * len(x)); y.append(3.0)
+        x, y = np.array(x, f32), np.array(y, f32)
+        sig = np.ones(N, np.int32)
+        got = _packed(x, y, sig, 0, K)
+        if got is None:
+            fell_back += 1
+            continue
+        answered += 1
+        assert got == _reference(x, y, sig, 0, K), (trial, m.tolist(), order.tolist())
+    assert answered > 50 and fell_back > 50
