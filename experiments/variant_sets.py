@@ -256,3 +256,54 @@ SETS_RETIRED_final_check = {
     "p_half0_after0": [(TC, _P_HALF, "      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);"),
                        (TC, _P_AFTER, "  __builtin_amdgcn_s_setprio(0);\n\n  // ------------------------------------------------------------ ids out")],
 }
+
+
+# ---- round 3: what bounds the tick?  "What-if" variants that REMOVE one resource's work (results are
+# wrong by construction: timing only) and a start stagger by hardware wave slot.
+_WT_DEF = ('#define WD_TC_STORE_WT(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(val) : "memory")')
+_NOSTORE = [(TC, _WT_DEF, '#define WD_TC_STORE_WT(ptr, val) asm volatile("" ::"v"(ptr), "v"(val) : "memory")')]
+_NOFETCH = [(TC, "  if (FUSED) {\n    // this wavefront's rows of both probability slabs -> LDS",
+             "  if (false) {\n    // this wavefront's rows of both probability slabs -> LDS")]
+_KNN_CALL = "    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank, in_order)) {"
+_NOCHAIN = [(TC, _KNN_CALL,
+             "    if (!([&]() {\n#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { const int j = ag + k + 1; nid[k] = j >= N ? j - N : j; }\n"
+             "      return true; })()) {")]
+
+
+def _stagger(ticks_per_slot):
+    return [(TC, "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;",
+             "  __builtin_amdgcn_s_setprio(3);\n  {\n    unsigned hw_;\n"
+             '    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));\n'
+             f"    const unsigned long long wait_ = (unsigned long long)((hw_ & 15u) * {ticks_per_slot}u);\n"
+             "    const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();\n"
+             "    while (__builtin_amdgcn_s_memrealtime() - t0_ < wait_) __builtin_amdgcn_s_sleep(4);\n  }\n  TcIn in;")]
+
+
+SETS["whatif"] = {
+    "base": [],
+    "nostore": _NOSTORE,
+    "nofetch": _NOFETCH,
+    "nochain": _NOCHAIN,
+    "nostore_nofetch": _NOSTORE + _NOFETCH,
+    "stagger75": _stagger(75),
+    "stagger150": _stagger(150),
+}
+
+
+# ---- round 3: geometry known at compile time (the reference injects num_agents / num_envs into its
+# kernels through a template header at JIT time, template_env_config.h:19-21): how much of the fused
+# tick is index arithmetic that folds away when N, the block size and the head sizes are constants?
+_FIXGEOM = [
+    (TC, "  const int N = a.N, K = EXACTK ? KMAX : a.K;\n  const int F = 7 * K + 1;\n  const int tid = threadIdx.x, T_ = blockDim.x;\n  const int epb = max(1, T_ / N);",
+     "  const int N = 105, K = EXACTK ? KMAX : a.K;\n  const int F = 7 * K + 1;\n  const int tid = threadIdx.x, T_ = 128;\n  const int epb = 1;"),
+    (TC, "tc_fast_impl<KM, true, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions)",
+     "tc_fast_impl<KM, true, true>(a, fz, tc_smem, 21, 21)"),
+]
+_NOFETCH_CLEAN = [(TC, "  if (FUSED) {\n    // this wavefront's rows of both probability slabs -> LDS",
+                   "  if (FUSED) { for (int i_ = tid; i_ < epb * N * n_acc; i_ += blockDim.x) { slab_acc[i_] = 1.0f / 21.0f; slab_turn[i_] = 1.0f / 21.0f; } }\n"
+                   "  if (false) {\n    // this wavefront's rows of both probability slabs -> LDS")]
+SETS["fixgeom"] = {
+    "base": [],
+    "fixgeom": _FIXGEOM,
+    "nofetch_clean": _NOFETCH_CLEAN,
+}

@@ -64,6 +64,12 @@ def _compare(w, orc, tag, stats):
         _TOTALS["near_tie_rows"] += len(bad)
     stats["rows"] += obs_ref.shape[0] * obs_ref.shape[1]
     _TOTALS["rows"] += obs_ref.shape[0] * obs_ref.shape[1]
+    if not orc.use_full_observation and orc.K <= orc.N - 1:
+        # nearest_neighbor_ids [E, N, K]: the reference order (distance, then id; -1 = fewer than K others in
+        # the game) for every agent that was in the game when the observation was generated
+        ids_dev = pull(w, "nearest_neighbor_ids").reshape(orc.nearest_ids.shape)
+        m = (obs_ref[..., -1] != 0) & (obs_dev == obs_ref).all(axis=2)
+        np.testing.assert_array_equal(ids_dev[m], orc.nearest_ids[m], err_msg=f"nearest_neighbor_ids {tag}")
 
 
 def _run_lockstep(cfg, E, ticks, seed, stats=None):
@@ -215,7 +221,7 @@ def test_bench_full_size_properties():
     (False, 6, 8, 30, 6, 23), (True, 6, 8, 30, 6, 23),
     (False, 30, 40, 17, 5, 9),     # probability rows longer than the register path (31 / 41 actions)
     (False, 1, 1, 100, 10, 5),     # two actions per head, the benchmark's agent count
-    (False, 3, 3, 130, 4, 3),      # more than 128 agents: LDS candidate lists
+    (False, 3, 3, 130, 4, 3),      # more than 128 agents: the generic kernel (K-pass selection)
     (True, 2, 5, 60, 3, 4),        # full observations whose width is a multiple of four (16-byte stores)
     (False, 70, 3, 10, 3, 2),      # action table larger than its LDS copy (71 > 64 entries)
 ])
@@ -293,6 +299,95 @@ def test_fused_tick_kernel(full_obs, acc_levels, turn_levels, runners, K, E):
     for c, p in zip(counts, probs):
         expected = p.cpu().numpy().reshape(-1, c.size).sum(0) * 40
         assert np.abs(c - expected).max() < 6 * np.sqrt(expected.max())
+
+
+def _near_tie_rows_c(orc, bad_rows):
+    """as _near_tie_rows, for the C oracle (distances rebuilt for the mismatching rows only)"""
+    from tests.hip_harness import ulp_diff
+
+    for e, i in bad_rows:
+        d = orc.neighbor_distances(int(e), int(i))
+        row = np.sort(d[np.isfinite(d)])[: orc.K + 1]
+        if len(row) < 2 or ulp_diff(row[1:], row[:-1]).min() > 2:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("full_obs,E,ticks", [(False, 2000, 44), (True, 64, 36)])
+def test_headline_fused_tick_full_size(full_obs, E, ticks):
+    """The (kernel, shape) pair bench.py reports: the fused HipTagContinuousTick_K10 at BASELINE
+    configs[2] -- 5 taggers + 100 runners, 20 + 20 levels (21-way heads), K = 10, num_envs = 2000 --
+    through RolloutEngine, EVERY replica compared with the C oracle on every tick: the sampled actions
+    draw for draw (Philox restated on the host, random.cu:51-85), then state / observations / rewards /
+    done and the post-reset state (reset.cu:9-75; 15-tick episodes, so every replica ends and restarts
+    at least twice).  Same for the full-observation variant (generic tick kernel) at N = 105.
+    Reference: example_envs/tag_continuous/tag_continuous.py:796-887."""
+    import torch
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from oracle.tag_continuous_c import TagContinuousCOracle
+    from tests.hip_harness import OBS, REW, pull, require_gpu
+    from warp_drive_amd.env_wrapper import EnvWrapper
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    require_gpu()
+    cfg = dict(BENCH_CFG, episode_length=15, use_full_observation=full_obs)
+    w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
+    w.reset_all_envs()
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=274880)
+    create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                      push_data_batch_placeholders=False)
+    N = w.n_agents
+    assert N == 105
+    rng = np.random.RandomState(3)
+    probs_host = [rng.dirichlet(np.ones(21), size=(E, N)).astype(np.float32) for _ in range(2)]
+    probs = [torch.from_numpy(p).cuda() for p in probs_host]
+    engine = RolloutEngine(w, sampler, probabilities=probs)
+    assert engine.fused
+    assert engine.step_kernel_name == ("HipTagContinuousTick" if full_obs else "HipTagContinuousTick_K10")
+    orc = TagContinuousCOracle(E, n_threads=min(32, os.cpu_count() or 1), **cfg)
+    np.testing.assert_array_equal(pull(w, OBS), orc.obs)
+    rng_words = np.zeros(4 + E * N, dtype=np.uint32)
+    near_tie = rows = finished_total = 0
+    restarts = np.zeros(E, dtype=np.int64)
+    for t in range(ticks):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        assert (rng_words[4:] == t).all()
+        engine.run(1)
+        torch.cuda.synchronize()
+        a = pull(w, "sampled_actions")
+        u0, u1 = fused_tick_uniforms(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
+        np.testing.assert_array_equal(a[..., 0], sample_actions_counting(probs_host[0], u0.reshape(E, N)))
+        np.testing.assert_array_equal(a[..., 1], sample_actions_counting(probs_host[1], u1.reshape(E, N)))
+        orc.step(a)
+        np.testing.assert_array_equal(pull(w, REW), orc.rewards, err_msg=f"rewards t={t}")
+        np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")  # still set for the trainer
+        fin = orc.done > 0
+        finished_total += int(fin.sum())
+        restarts += fin
+        obs_before_reset = orc.obs[~fin].copy()
+        orc.reset_done_envs()
+        for name, attr in STATE:
+            np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
+        obs_dev = pull(w, OBS)
+        np.testing.assert_array_equal(obs_dev[fin], orc.obs[fin], err_msg=f"reset observation t={t}")
+        live = np.flatnonzero(~fin)
+        if not np.array_equal(obs_dev[live], obs_before_reset):
+            assert not full_obs, f"full-obs mismatch t={t}"
+            bad = np.argwhere((obs_dev[live] != obs_before_reset).any(axis=2))
+            bad[:, 0] = live[bad[:, 0]]
+            assert _near_tie_rows_c(orc, bad), f"obs mismatch that is not a near-tie t={t}: {bad[:5]}"
+            near_tie += len(bad)
+        rows += E * N
+    _TOTALS["near_tie_rows"] += near_tie
+    _TOTALS["rows"] += rows
+    assert restarts.min() >= 2 and finished_total >= 2 * E, (restarts.min(), finished_total)
+    assert near_tie <= max(2, rows // 100000), (near_tie, rows)
 
 
 def _push_state(w, **arrays):
@@ -423,9 +518,8 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K):
 
 @pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (525, 5, False), (1020, 3, False)])
 def test_many_agents_paths(n_runners, K, full_obs):
-    """replicas larger than the bit-mask path: 129..512 agents use the LDS candidate lists of the
-    register-resident search, more than 512 agents the generic entry point (one block of up to 1024
-    threads per replica)"""
+    """replicas of more than 128 agents: the generic entry points (tc_generic_impl: K-pass selection,
+    one block of up to 1024 threads per replica)"""
     cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=30.0, episode_length=6, seed=13,
                max_acceleration=0.2, min_acceleration=-0.2, num_acceleration_levels=5, num_turn_levels=5,
                use_full_observation=full_obs, num_other_agents_observed=K, tagging_distance=0.2,
