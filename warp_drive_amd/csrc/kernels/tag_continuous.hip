@@ -118,6 +118,7 @@ struct TcTables {
   int *tagger_ids;   // [N] ascending
   float *acc_tab, *turn_tab;  // action tables (n_acc, n_turn entries; capacity WD_TC_TAB each)
   int *wave_cnt;     // [16] taggers per wavefront (rank computation)
+  int *live_cnt;     // [16] agents still in the game per wavefront (compaction of the search, one replica per block)
   int *tstep, *nrun; // [epb]
   float *tfrac;      // [epb] float(t) / episode_length
   int *doneflag;     // [epb] replica finished on this tick (fused tick only)
@@ -130,6 +131,7 @@ __device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, i
   t.acc_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
   t.turn_tab = (float *)(p + off); off += 4 * WD_TC_TAB;
   t.wave_cnt = (int *)(p + off); off += 4 * 16;
+  t.live_cnt = (int *)(p + off); off += 4 * 16;
   t.tstep = (int *)(p + off); off += 4 * epb;
   t.nrun = (int *)(p + off); off += 4 * epb;
   t.tfrac = (float *)(p + off); off += 4 * epb;
@@ -843,6 +845,33 @@ __device__ __forceinline__ void tc_flush_run(const float *stage, float *dst, int
   if (lane < n - tail0) dst[tail0 + lane] = stage[mis + tail0 + lane];
 }
 
+// nearest_neighbor_ids rows from the block-local 16-bit ids in LDS: n dwords starting at `dst`, dword i =
+// id i of the run (0xffff -> -1; block-local -> replica-local when a block holds several replicas);
+// aligned 16-byte write-through stores, single dwords before / after the aligned part.
+__device__ __forceinline__ void tc_flush_ids(const unsigned short *src, int *dst, int n, int lane, int row0, int N,
+                                             float invK, float invN, bool one_replica) {
+  const int mis = (int)(((size_t)dst >> 2) & 3);
+  const int head = min(n, (4 - mis) & 3);
+  const int nvec = (n - head) >> 2;
+  const int tail0 = head + 4 * nvec;
+  auto conv = [&](int i) -> int {
+    int v = (int)(short)src[i];
+    if (!one_replica && v >= 0) {
+      const int row = row0 + (int)(((float)i + 0.5f) * invK);  // i / K, exact (see the gather)
+      v -= (int)(((float)row + 0.5f) * invN) * N;
+    }
+    return v;
+  };
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  for (int q = lane; q < nvec; q += 64) {
+    const int i = head + 4 * q;
+    const v4i v = {conv(i), conv(i + 1), conv(i + 2), conv(i + 3)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + i), "v"(v) : "memory");
+  }
+  if (lane < head) dst[lane] = conv(lane);
+  if (lane < n - tail0) dst[tail0 + lane] = conv(tail0 + lane);
+}
+
 // rows of a wavefront's staging buffer: the host sizes the buffer with the same formula
 // (envs/tag_continuous.py: lds_bytes_fast)
 #define WD_TC_STAGE_TARGET 5400  // bytes of rows per wavefront (19 rows of 71 floats)
@@ -858,6 +887,9 @@ struct TcFastLds {
                          // to a multiple of 4, plus 8 entries of padding that the search's prefetches may read
   int *sig;              // [A] still_in_the_game before this tick's tagging
   int *tagcnt;           // [A] tags credited to a tagger this tick
+  float2 *xyc;           // one replica per block: [NP] positions of the agents IN THE GAME, packed in ascending id order
+                         // (the candidates and the searchers of the neighbour search); else == xy
+  signed char *cid;      // one replica per block: [1 + N] cid[1 + c] = id of the c-th agent in the game, cid[0] = -1
   unsigned short *ids;   // [A][K] block-local neighbour indices (0xffff = none)
   float *stage;          // [n_waves][stage_dwords] wave-private staging buffers
   int stage_dwords;
@@ -865,7 +897,7 @@ struct TcFastLds {
 };
 
 __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, int N, int K, int n_waves,
-                                                   size_t min_area_bytes) {
+                                                   size_t min_area_bytes, bool compact) {
   TcFastLds l;
   const size_t A = (size_t)epb * N;
   const int F = 7 * K + 1;
@@ -874,6 +906,13 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   l.xy = (float2 *)(p0 + off); off += 8 * (size_t)epb * (((N + 3) & ~3) + 8);  // see TcFastLds::xy
   l.sig = (int *)(p0 + off); off += 4 * A;
   l.tagcnt = (int *)(p0 + off); off += 4 * A;
+  l.xyc = l.xy;
+  l.cid = nullptr;
+  if (compact) {  // (the host adds the same bytes: envs/tag_continuous.py lds_bytes)
+    off = tc_align16(off);
+    l.xyc = (float2 *)(p0 + off); off += 8 * (size_t)(((N + 3) & ~3) + 8);
+    l.cid = (signed char *)(p0 + off); off += tc_align16((size_t)N + 1);
+  }
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
   l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F) * F) / 4) + 4;
   l.stage = (float *)(p0 + off); off += (size_t)4 * l.stage_dwords * n_waves;
@@ -892,8 +931,16 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const int epb = max(1, T_ / N);
   const int n_waves = (T_ + 63) >> 6, wave = tid >> 6, lane = tid & 63;
   const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
+  // One replica per block (more than 64 agents: the BASELINE shape): the neighbour search runs over
+  // the agents that are still IN THE GAME only, packed in ascending id order -- as candidates (the
+  // chain is as long as the live list, not N) and as searchers (searcher lane c works for the c-th
+  // live agent, so a wavefront whose lanes are all >= the live count skips the search).  Under the
+  // reference's own benchmark policy (uniform random actions) 54 of 105 agents are in the game on
+  // average over a 500-tick episode (105 at the start, ~27 at the end).  Packing preserves the id
+  // order, so ties break exactly as before; ids are translated back through `cid`.
+  const bool compact = (epb == 1);
   const TcFastLds l = tc_carve_fast(smem, epb, N, K, n_waves,
-                                    FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
+                                    FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0, compact);
   const TcTables &tb = l.tb;
   float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
   float *const stage = l.stage + (size_t)wave * l.stage_dwords;
@@ -926,11 +973,25 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const int li = tid;           // index into LDS arrays (= el * N + ag)
   const int agents_here = min(epb, a.E - env0) * N;
   int2 sampled = in.sampled;
+  const unsigned long long live_mask = __ballot(active && in.sg != 0);
+  if (compact && lane == 0) tb.live_cnt[wave] = __popcll(live_mask);
   if (FUSED) {
     if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
     sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
   }
   __syncthreads();  // tables are published; every wavefront is done with the slabs
+  // packed index of this lane's agent among the agents in the game, and their number
+  int my_c = ag, n_live = N;
+  if (compact) {
+    int before = 0;
+    n_live = 0;
+    for (int w2 = 0; w2 < n_waves; ++w2) {
+      const int c = tb.live_cnt[w2];
+      before += (w2 < wave) ? c : 0;
+      n_live += c;
+    }
+    my_c = before + __popcll(live_mask & ((1ull << lane) - 1ull));
+  }
 
   // ------------------------------------------------------------ move
   float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
@@ -942,6 +1003,13 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     // agents out of the game are pushed to +BIG for the neighbour search only; every other
     // consumer (taggers are never out of the game) reads real positions
     l.xy[el * NP + ag] = make_float2(sg ? m.x : WD_BIG, m.y);
+    if (compact) {
+      if (sg) {
+        l.xyc[my_c] = make_float2(m.x, m.y);
+        l.cid[1 + my_c] = (signed char)ag;
+      }
+      if (ag == 0) l.cid[0] = -1;
+    }
     l.feat[li] = m.ft;
     l.sig[li] = sg;
     l.tagcnt[li] = 0;
@@ -969,78 +1037,69 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // for: all their entries are "none")
   bool in_order = true;
   __builtin_amdgcn_s_setprio(2);
-  if (active && sg) {
+  // searcher lane `ag` works for the ag-th agent in the game (packed) or for its own agent
+  const bool searcher = compact ? (tid < n_live) : (active && sg != 0);  // (tid == ag for these lanes)
+  const float2 *const sxy = compact ? l.xyc : l.xy + el * NP;
+  const int n_cand = compact ? n_live : N;
+  int row_agent = ag;  // the agent whose row this lane's search fills
+  if (searcher) {
     // one pass with packed keys; a lane with three candidates inside 256 ulps at the cut (~1e-7 per
     // agent) repeats the search with the two-pass one
-    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank, in_order)) {
+    if (!tc_knn_packed<KMAX>(sxy, ag, n_cand, K, nid, rank, in_order)) {
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
-      tc_knn_registers<KMAX>(l.xy + el * NP, ag, N, K, nid2, rank2);
+      tc_knn_registers<KMAX>(sxy, ag, n_cand, K, nid2, rank2);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = rank2[k]; }
       nid[KMAX] = -1;
       rank[KMAX] = KMAX;
       in_order = false;
     }
+    if (compact) {  // packed indices -> agent ids (cid[0] = -1 stands for "none")
+      row_agent = l.cid[1 + ag];
+#pragma unroll
+      for (int k = 0; k <= KMAX; ++k) nid[k] = l.cid[1 + nid[k]];
+    }
   }
   __builtin_amdgcn_s_setprio(0);
 
-  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)
-  int wrow0 = wave * 64;
-  int wrows = max(0, min(64, agents_here - wrow0));
+  // ------------------------------------------------------------ ids out: block-local 16-bit neighbour
+  // ids per agent row in LDS (0xffff = none), read by the gather and turned into the
+  // `nearest_neighbor_ids` rows after the barrier.  Entry k goes to slot k at fixed offsets; the few
+  // lanes whose entries are not in order (a near-tie, fewer than K agents in the game) then rewrite
+  // their rows by rank.
   {
-    // neighbour ids: block-local 16-bit copies for the gather, and the [E, N, K] output through
-    // the staging buffer (rows of K dwords, contiguous over the wavefront's agents).  Every lane
-    // writes entry k to slot k at fixed offsets; the few lanes whose entries are not in order
-    // (a near-tie, fewer than K agents in the game) then rewrite their rows by rank.
-    int *const istage = (int *)stage;
-    int *const nb_out = a.nearest_ids + ((long)env0 * N + wrow0) * K;
-    const int rows_per_pass = max(1, min(64, (l.stage_dwords - 4) / K));
     const int ebase = el * N;
     const bool any_out_of_order = __ballot(!in_order) != 0ull;  // wave-uniform
-    const unsigned none_mask = (active && sg) ? 0u : 0xffffffffu;
-    if (active) {
-      unsigned short *const idrow = l.ids + (size_t)li * K;
+    if (active && sg == 0) {  // out of the game: no neighbours
+      unsigned short *const own = l.ids + (size_t)li * K;
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)  // (in-order rows hold K ids, or none at all: one mask per lane)
-        if (k < K) idrow[k] = (unsigned short)((unsigned)(ebase + nid[k]) | none_mask);
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) own[k] = 0xffff;
+    }
+    if (searcher) {
+      unsigned short *const idrow = l.ids + (size_t)(ebase + row_agent) * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)  // (an in-order row holds K ids)
+        if (k < K) idrow[k] = (unsigned short)(ebase + nid[k]);
       if (any_out_of_order && !in_order) {
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k)  // (K of the KMAX + 1 entries have a rank < K)
           if (rank[k] < K) idrow[rank[k]] = (unsigned short)(nid[k] < 0 ? 0xffff : ebase + nid[k]);
       }
     }
-    for (int r0 = 0; r0 < wrows; r0 += rows_per_pass) {
-      const int rc = min(rows_per_pass, wrows - r0);
-      const int mis = (int)(((size_t)(nb_out + (long)r0 * K) >> 2) & 3);
-      if (lane >= r0 && lane < r0 + rc) {
-        int *const row = istage + mis + (lane - r0) * K;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K) row[k] = nid[k];
-        if (any_out_of_order && !in_order) {
-#pragma unroll
-          for (int k = 0; k <= KMAX; ++k)
-            if (rank[k] < K) row[rank[k]] = nid[k];
-        }
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      tc_flush_run((const float *)istage, (float *)(nb_out + (long)r0 * K), rc * K, lane);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-    }
   }
   // ------------------------------------------------------------ gather: the block's rows are split
   // evenly over its wavefronts (105 agents: 53 + 52 rows instead of 64 + 41: one chunk less on the
   // longer side), so a wavefront also gathers rows whose neighbours another wavefront found
   __syncthreads();
-  {
-    const int rpw = (agents_here + n_waves - 1) / n_waves;
-    wrow0 = wave * rpw;
-    wrows = max(0, min(rpw, agents_here - wrow0));
-  }
+  const int rpw = (agents_here + n_waves - 1) / n_waves;
+  const int wrow0 = wave * rpw;
+  const int wrows = max(0, min(rpw, agents_here - wrow0));
+  // nearest_neighbor_ids [E, N, K]: this wavefront's rows, straight from the 16-bit LDS copies
+  tc_flush_ids(l.ids + (size_t)wrow0 * K, a.nearest_ids + ((long)env0 * N + wrow0) * K, wrows * K, lane, wrow0, N,
+               invK, invN, epb == 1);
   {
     // observation rows, R rows per chunk: work item = (row, neighbour slot) -> 7 values at
     // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run.

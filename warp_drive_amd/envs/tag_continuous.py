@@ -318,12 +318,14 @@ class TagContinuous(CUDAEnvironmentContext):
             stage_rows = max(1, min(64, self.STAGE_TARGET_BYTES // (4 * F)))
             stage_dwords = align16(4 * stage_rows * F) // 4 + 4
             area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
+            if epb == 1:  # packed positions of the agents in the game + the packed-index -> id table
+                area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(N + 1)
             area = align16(area + 2 * A * K) + 4 * stage_dwords * n_waves  # 16-bit neighbour ids, staging
         else:
             area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
         if fused:  # the work area doubles as the two probability slabs (global_load_lds targets)
             area = max(area, align16(4 * A * len(self.acceleration_actions)) + align16(4 * A * len(self.turn_actions)))
-        return align16(area) + 4 * N + 4 * (2 * 64 + 16) + 4 * 4 * epb + 16   # + tagger list, action tables, per-replica scalars
+        return align16(area) + 4 * N + 4 * (2 * 64 + 32) + 4 * 4 * epb + 16   # + tagger list, action tables, per-wavefront counts, per-replica scalars
 
     def _geometry(self):
         """(replicas per block, block, grid): whole replicas packed into blocks of at most 256 threads
