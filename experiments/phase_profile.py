@@ -2,7 +2,7 @@
 """Per-wavefront phase timeline of the fused TagContinuous tick (variant "prof" of
 experiments/variant_sets.py: s_memtime stamps at the phase boundaries, written through a
 __device__ pointer the harness sets).  Run on the GPU box after `variants.py build profile`:
-    python experiments/phase_profile.py [variant-name] [num_envs]"""
+    python experiments/phase_profile.py [variant-name] [num_envs] [episode tick of the stamped launch]"""
 import os
 import sys
 
@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 name = sys.argv[1] if len(sys.argv) > 1 else "prof"
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+T_STAMP = int(sys.argv[3]) if len(sys.argv) > 3 else 300  # (episodes are 500 ticks; the live-agent count falls along them)
 os.environ["WD_HSACO"] = os.path.join(ROOT, "build", "variants", f"{name}.hsaco")
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import time
@@ -43,6 +44,10 @@ t0 = time.perf_counter()
 engine.run(1000)
 torch.cuda.synchronize()
 print(f"=== {name}: wall per tick {(time.perf_counter() - t0) / 1000 * 1e6:.2f} us (stamped build)")
+engine.run((T_STAMP - 1300) % 500)
+torch.cuda.synchronize()
+live = w.cuda_data_manager.pull_data_from_device("still_in_the_game").sum(axis=1).mean()
+print(f"stamped launch = tick {T_STAMP} of an episode, {live:.1f} agents in the game")
 drv.memset(buf, 0, n_waves * 16 * 8)
 torch.cuda.synchronize()
 engine.run(1)
@@ -53,12 +58,15 @@ drv.synchronize()
 st = raw.reshape(-1, 16).astype(np.int64)
 fell_back = st[:, 8] > 0
 print(f"wavefronts with a lane outside the in-order exit of the search (exact ranking branch): {fell_back.sum()} of {(st[:, 13] > 0).sum()}")
+searched = st[:, 7] > 0
+print(f"wavefronts that ran the search: {searched.sum()} of {(st[:, 13] > 0).sum()}")
+st[:, 7] = np.where(searched, st[:, 7], st[:, 6])
 st[:, 8] = np.where(fell_back, st[:, 8], st[:, 7])
 names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "knn key chain", "(ranking branch entered)", "knn ids / ranking branch",
          "ids flushed", "obs gathered+flushed", "barrier3", "rewards/end"]
 for wv, label in ((0, "wave 0 of each block (64 agents)"), (1, "wave 1 of each block (41 agents)")):
     s = st[wv::2]
-    ok = (s[:, 7] > 0) & (s[:, 13] > 0)
+    ok = (s[:, 6] > 0) & (s[:, 13] > 0)
     s = s[ok]
     print(f"--- {label}: {ok.sum()} waves; mean / p10 / p90 shader cycles per phase")
     for k in range(1, 14):
@@ -74,7 +82,7 @@ pc = lambda a: " ".join(f"{np.percentile(a, q):6.2f}" for q in (0, 10, 50, 90, 9
 print("percentiles 0/10/50/90/99/100 (us): wave start", pc(start), "| wave end", pc(end), "| lifetime", pc(end - start))
 # absolute timeline of the phase boundaries (us since the first wave started), wave 0 only
 s0 = st[0::2]
-s0 = s0[(s0[:, 7] > 0) & (s0[:, 13] > 0)]
+s0 = s0[(s0[:, 6] > 0) & (s0[:, 13] > 0)]
 ghz = ((s0[:, 13] - s0[:, 0]) / ((s0[:, 15] - s0[:, 14]) * 10.0)).mean()
 base = (s0[:, 14] - t0) / 100.0
 print("phase boundary, us since first wave start (p10 / p50 / p90), wave 0:")

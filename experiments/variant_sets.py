@@ -41,15 +41,15 @@ PROFILE = [
      "  if (env0 >= a.E) return;\n  TC_STAMP(1);\n  const int env = env0 + el;"),
     (TC, "  __syncthreads();  // tables are published; every wavefront is done with the slabs\n",
      "  TC_STAMP(2);\n  __syncthreads();\n  TC_STAMP(3);\n"),
-    (TC, "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  __syncthreads();\n\n  // ------------------------------------------------------------ tags",
-     "      tb.nrun[el] = a.num_runners[env];\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
+    (TC, "      tb.nrun[el] = in.nrun;\n    }\n  }\n  __syncthreads();\n\n  // ------------------------------------------------------------ tags",
+     "      tb.nrun[el] = in.nrun;\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
     (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX + 1], rank[KMAX + 1];",
      "  TC_STAMP(6);\n  int nid[KMAX + 1], rank[KMAX + 1];"),
     (TC, "  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry"),
     # slot 8 is written only by wavefronts in which some lane leaves the in-order exit of the one-pass search
     (TC, "  in_order = apart;\n  if (!apart) {", "  in_order = apart;\n  if (!apart) {\n    if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();"),
-    (TC, "  // ------------------------------------------------------------ ids out (rows of this wavefront's own lanes)",
-     "  TC_STAMP(9);\n  // ---- ids out"),
+    (TC, "  // ------------------------------------------------------------ ids out: block-local 16-bit neighbour",
+     "  TC_STAMP(9);\n  // ---- ids out: block-local 16-bit neighbour"),
     (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
     (TC, "  __syncthreads();  // every runner's tag is counted\n", "  TC_STAMP(11);\n  __syncthreads();\n  TC_STAMP(12);\n"),
     (TC, "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n}\n", "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n  TC_STAMP(13); TC_STAMP_RT(15);\n}\n"),

@@ -145,6 +145,9 @@ struct TcIn {
   float dir, acc, speed, x, y, skill;
   int2 sampled;
   uint32_t epoch;
+  float step_reward;   // step_rewards[agent]
+  int tstep, nrun;     // lane of agent 0: _timestep_ / num_runners of the replica
+  float tab_acc, tab_turn;  // entry `tid` of the two action tables (tables of at most WD_TC_TAB entries)
 };
 
 template <bool FUSED>
@@ -158,6 +161,13 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
   in.sg = 0; in.type = 0; in.dir = in.acc = in.speed = in.x = in.y = in.skill = 0.f;
   in.sampled = make_int2(0, 0);
   in.epoch = 0u;
+  in.step_reward = 0.f;
+  in.tstep = in.nrun = 0;
+  in.tab_acc = in.tab_turn = 0.f;
+  if (n_acc <= WD_TC_TAB && n_turn <= WD_TC_TAB) {  // (a block has at least 64 threads)
+    if (tid < n_acc) in.tab_acc = a.acc_actions[tid];
+    if (tid < n_turn) in.tab_turn = a.turn_actions[tid];
+  }
   if (active) {
     in.sg = a.sig_arr[gi];
     in.dir = a.direction[gi];
@@ -167,6 +177,12 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
     in.y = a.loc_y[gi];
     in.skill = a.skill_levels[ag];
     in.type = a.agent_types[ag];
+    // (the counters return in order: a load issued after the tick's stores would wait for all of them)
+    in.step_reward = a.step_rewards[ag];
+    if (ag == 0) {
+      in.tstep = a.timestep[env];
+      in.nrun = a.num_runners[env];
+    }
     if (!FUSED) in.sampled = ((const int2 *)a.actions)[gi];
     if (FUSED) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
   }
@@ -184,17 +200,20 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
 // ---- replica-independent tables: ascending tagger list, action tables.
 // Returns the number of taggers.  Ends WITHOUT a barrier: the caller's next barrier publishes them.
 __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs &a, int N, int n_acc, int n_turn,
-                                               bool tab_in_lds) {
+                                               bool tab_in_lds, const TcIn &in) {
   const int tid = threadIdx.x, T_ = blockDim.x;
-  if (tab_in_lds) {
-    for (int i = tid; i < n_acc; i += T_) tb.acc_tab[i] = a.acc_actions[i];
-    for (int i = tid; i < n_turn; i += T_) tb.turn_tab[i] = a.turn_actions[i];
+  const int my_type = in.type;
+  if (tab_in_lds) {  // (entries loaded up front, before the probability slabs)
+    if (tid < n_acc) tb.acc_tab[tid] = in.tab_acc;
+    if (tid < n_turn) tb.turn_tab[tid] = in.tab_turn;
   }
   int n_taggers = 0;
   // rank of a tagger = number of taggers with a smaller id: wave ballots + per-wave counts
   const int wave = tid >> 6, lane = tid & 63, n_waves = (T_ + 63) >> 6;
   if (N <= T_) {  // usual case: one barrier
-    const int ty = (tid < N) ? a.agent_types[tid] : 0;
+    // (thread tid < N is agent tid of the block's first replica: its type is among the loads issued up
+    // front, BEFORE the probability slabs, so waiting for it does not wait for the slabs)
+    const int ty = (tid < N) ? my_type : 0;
     const unsigned long long m = __ballot(ty == 1);
     if (lane == 0) tb.wave_cnt[wave] = __popcll(m);
     __syncthreads();
@@ -350,9 +369,9 @@ __device__ __forceinline__ bool tc_find_tag(const TcArgs &a, const TcTables &tb,
 // ---- rewards / done of one agent (:655-678, :880-883); call after the barrier that follows the tags
 __device__ __forceinline__ void tc_finish_agent(const TcArgs &a, const TcTables &tb, int el, int ag, int gi, int env,
                                                 int sg, bool is_runner, bool tagged, int tagcnt, float edge_pen,
-                                                bool fused) {
+                                                float step_reward, bool fused) {
   float rew = 0.0f;
-  if (sg) { rew += edge_pen; rew += a.step_rewards[ag]; }       // :655-658
+  if (sg) { rew += edge_pen; rew += step_reward; }              // :655-658
   if (tagged) rew += a.tag_penalty;                             // :664
   for (int k = 0; k < tagcnt; ++k) rew += a.tag_reward;         // :665, one add per tag
   const bool still_runner = is_runner && !(tagged && a.runner_exits);
@@ -854,22 +873,23 @@ __device__ __forceinline__ void tc_flush_ids(const unsigned short *src, int *dst
   const int head = min(n, (4 - mis) & 3);
   const int nvec = (n - head) >> 2;
   const int tail0 = head + 4 * nvec;
-  auto conv = [&](int i) -> int {
-    int v = (int)(short)src[i];
-    if (!one_replica && v >= 0) {
-      const int row = row0 + (int)(((float)i + 0.5f) * invK);  // i / K, exact (see the gather)
-      v -= (int)(((float)row + 0.5f) * invN) * N;
-    }
-    return v;
+  // replica-local id of run element i holding block-local id v (v < 0: none)
+  auto local = [&](int v, int i) -> int {
+    if (one_replica) return v;
+    const int row = row0 + (int)(((float)i + 0.5f) * invK);  // i / K, exact (see the gather)
+    const int sub = (int)(((float)row + 0.5f) * invN) * N;
+    return v - (v >= 0 ? sub : 0);
   };
   typedef int v4i __attribute__((ext_vector_type(4)));
   for (int q = lane; q < nvec; q += 64) {
     const int i = head + 4 * q;
-    const v4i v = {conv(i), conv(i + 1), conv(i + 2), conv(i + 3)};
+    const int r0 = (int)(short)src[i], r1 = (int)(short)src[i + 1], r2 = (int)(short)src[i + 2],
+              r3 = (int)(short)src[i + 3];
+    const v4i v = {local(r0, i), local(r1, i + 1), local(r2, i + 2), local(r3, i + 3)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + i), "v"(v) : "memory");
   }
-  if (lane < head) dst[lane] = conv(lane);
-  if (lane < n - tail0) dst[tail0 + lane] = conv(tail0 + lane);
+  if (lane < head) dst[lane] = local((int)(short)src[lane], lane);
+  if (lane < n - tail0) dst[tail0 + lane] = local((int)(short)src[tail0 + lane], tail0 + lane);
 }
 
 // rows of a wavefront's staging buffer: the host sizes the buffer with the same formula
@@ -964,7 +984,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
-  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds);
+  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds, in);
   if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
 
   const int env = env0 + el;
@@ -1014,11 +1034,11 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     l.sig[li] = sg;
     l.tagcnt[li] = 0;
     if (ag == 0) {
-      const int t = a.timestep[env] + 1;  // :800
+      const int t = in.tstep + 1;  // :800
       a.timestep[env] = t;
       tb.tstep[el] = t;
       tb.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474
-      tb.nrun[el] = a.num_runners[env];
+      tb.nrun[el] = in.nrun;
     }
   }
   __syncthreads();
@@ -1177,7 +1197,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   __syncthreads();  // every runner's tag is counted
 
   // ------------------------------------------------------------ rewards / done
-  if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, FUSED);
+  if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, in.step_reward, FUSED);
   if (FUSED) {
     __syncthreads();  // doneflag
     bool any = false;
@@ -1262,7 +1282,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
-  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds);
+  const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds, in);
   if (env0 >= a.E) return;
 
   while (true) {
@@ -1289,11 +1309,11 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
       l.sig[li] = sg;
       l.tagcnt[li] = 0;
       if (ag == 0) {
-        const int t = a.timestep[env] + 1;
+        const int t = in.tstep + 1;
         a.timestep[env] = t;
         tb.tstep[el] = t;
         tb.tfrac[el] = (float)((double)t / (double)a.T);
-        tb.nrun[el] = a.num_runners[env];
+        tb.nrun[el] = in.nrun;
       }
     }
     __syncthreads();
@@ -1410,7 +1430,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
     }
 
     // ------------------------------------------------------------ rewards / done
-    if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, FUSED);
+    if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, in.step_reward, FUSED);
     __syncthreads();  // (also: all stores of the tick to this replica's rows are issued)
     if (FUSED) tc_reset_finished(a, fz, tb, env0, epb);
     env0 += gridDim.x * epb;
