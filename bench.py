@@ -12,10 +12,19 @@ value = total env-steps of all ranks / max-over-ranks wall time of the timed reg
 Replicas shard trivially (weak scaling): no collective in the data path; for N > 1 the
 only RCCL traffic is the barrier + the max-reduction of the timing.
 
-The timed region holds the K launches and nothing else (no event records).  The dominant
-kernel's average launch duration (roofline.achieved) is measured with HIP events on the launch
-stream around groups of 8 back-to-back launches, in two passes of 512 launches just before and
-just after the timed region.
+The cost of a TagContinuous tick follows the number of agents still in the game, which falls along an
+episode (all replicas of a run restart together, as in WarpDrive training: 105 agents at tick 0, ~27 at
+tick 500 under the uniform random policy).  The timed region therefore sits at a defined place of the
+episode: it starts on an episode boundary when K covers at least one episode (the default K = 2000 is
+four whole episodes, i.e. the episode average), otherwise it is centred on the middle of an episode,
+whose tick costs what the episode costs on average (config.episode_window says where; the `episode`
+object carries the whole profile measured in the same run).
+
+The timed region holds the K launches and nothing else (no event records).  The dominant kernel's
+average launch duration (roofline.achieved) is measured with HIP events on the launch stream around
+windows of 10 back-to-back launches, over one whole episode just before and one just after the timed
+region.  `ms_per_step_spread` = min / median / max of five repeats of the timed region at the same place
+of the episode (`value` is the first).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
         (N > 1 without a launcher: bench.py starts its own N ranks through torch.distributed.run)
@@ -23,7 +32,6 @@ Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import hashlib
 import json
 import os
@@ -45,6 +53,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# Shader cycles per wave-instruction per SIMD with four wavefronts resident (experiments/ubench,
+# profiles/r02_ubench.txt), by the PMC counter classes of scripts/pmc_mix_tc.sh: v_add/mul_f32 ~1.2,
+# v_fma_f32 ~2, integer / min / max / med3 / compare ~2.9 (the INT32 class of the tick is dominated by
+# v_med3_u32), conversions ~2.9, float64 and 64-bit integer ~4, transcendental ~6, everything else
+# (moves, selects, lane ops) ~2.5
+VALU_CYCLES = {"ADD_F32": 1.2, "MUL_F32": 1.2, "FMA_F32": 2.0, "INT32": 2.9, "CVT": 2.9, "INT64": 4.0,
+               "ADD_F64": 4.0, "MUL_F64": 4.0, "FMA_F64": 4.0, "TRANS_F32": 6.0, "OTHER": 2.5}
+SIMDS = 256 * 4
+
 BENCH_CFG = dict(num_taggers=5, num_runners=100, grid_length=20.0, episode_length=500, max_acceleration=0.1,
                  min_acceleration=-0.1, max_turn=2.356, min_turn=-2.356, num_acceleration_levels=20,
                  num_turn_levels=20, skill_level_runner=1.0, skill_level_tagger=1.0, max_speed=1.0, seed=274880,
@@ -63,58 +80,59 @@ def step_algorithmic_bytes(N, K, full_obs):
     return 4 * N * (5 + 1 + 2) + 4 * N * (5 + 1 + 1 + 1 + F + k_ids) + 24
 
 
+def valu_roofline(kernel, num_envs, full_obs, kernel_us):
+    """Second roofline ("report both, grade on HBM"): the VALU issue time of one launch.
+    Dynamic instruction counts per class come from the PMC passes of scripts/pmc_mix_tc.sh
+    (profiles/pmc_mix.json, averaged over whole episodes), quoted only when they were collected on exactly
+    the code object loaded now; cycles per instruction class from experiments/ubench (VALU_CYCLES)."""
+    path = os.path.join(ROOT, "profiles", "pmc_mix.json")
+    try:
+        from warp_drive_amd.managers import hip_driver
+
+        sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
+        rec = json.load(open(path))
+        if (rec.get("hsaco_sha256") != sha or rec.get("kernel") != kernel or rec.get("num_envs") != num_envs
+                or bool(rec.get("full_obs")) != full_obs):
+            return None
+        c = rec["counters_per_launch"]
+        classes = {k: float(c.get("SQ_INSTS_VALU_" + k, 0.0)) for k in VALU_CYCLES if k != "OTHER"}
+        classes["OTHER"] = max(0.0, float(c["SQ_INSTS_VALU"]) - sum(classes.values()))
+        cycles = sum(classes[k] * VALU_CYCLES[k] for k in classes)  # summed over all wavefronts of a launch
+        clock_ghz = float(rec.get("shader_clock_ghz", 2.3))
+        issue_us = cycles / SIMDS / (clock_ghz * 1e3)
+        return {"bound": "valu issue", "wave_insts": float(c["SQ_INSTS_VALU"]) / float(c["SQ_WAVES"]),
+                "waves": float(c["SQ_WAVES"]), "insts_by_class_per_wave": {k: v / float(c["SQ_WAVES"]) for k, v in classes.items()},
+                "cycles_per_inst_by_class": VALU_CYCLES, "shader_clock_ghz": clock_ghz,
+                "issue_bound_us": issue_us, "frac": issue_us / kernel_us if kernel_us > 0 else None,
+                "active_lanes_per_inst": float(c.get("SQ_THREAD_CYCLES_VALU", 0.0)) / max(float(c["SQ_INSTS_VALU"]), 1.0),
+                "source": "profiles/pmc_mix.json"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, target_seconds=12.0):
     """The oracle's C restatement (oracle/csrc/wd_oracle.c) timed on this host's cores,
     on a bounded sample of the same workload.  Reported, never the optimisation target."""
-    from oracle import build as obuild
-    from oracle.tag_continuous_np import TagContinuousOracle
+    from oracle.tag_continuous_c import TagContinuousCOracle
 
-    lib = ctypes.CDLL(obuild.build())
     cores = os.cpu_count() or 1
     E = 32 * cores
-    orc = TagContinuousOracle(num_envs=E, **cfg)  # seeded start state (test infrastructure)
-    N, K = orc.N, orc.K
-
-    class Cfg(ctypes.Structure):
-        _fields_ = [("n_envs", ctypes.c_int), ("n_agents", ctypes.c_int), ("episode_length", ctypes.c_int),
-                    ("K", ctypes.c_int), ("use_full_observation", ctypes.c_int), ("runner_exits", ctypes.c_int),
-                    ("grid_length", ctypes.c_float), ("max_speed", ctypes.c_float),
-                    ("edge_hit_penalty", ctypes.c_float), ("margin", ctypes.c_float),
-                    ("tag_reward", ctypes.c_float), ("tag_penalty", ctypes.c_float), ("end_reward", ctypes.c_float),
-                    ("n_acc", ctypes.c_int), ("n_turn", ctypes.c_int)]
-
-    c = Cfg(E, N, orc.T, K, int(orc.use_full_observation), int(orc.runner_exits), float(orc.grid_length),
-            float(orc.max_speed), float(orc.edge_hit_penalty), float(orc.distance_margin_for_reward),
-            float(orc.tag_reward_for_tagger), float(orc.tag_penalty_for_runner),
-            float(orc.end_of_game_reward_for_runner), len(orc.acceleration_actions), len(orc.turn_actions))
-    st = {k: np.ascontiguousarray(getattr(orc, k)) for k in
-          ("loc_x", "loc_y", "speed", "direction", "acceleration", "edge_pen", "sig", "num_runners", "timestep", "done")}
-    obs = np.zeros((E, N, orc.obs_dim), np.float32)
-    rew = np.zeros((E, N), np.float32)
+    orc = TagContinuousCOracle(E, n_threads=cores, **cfg)  # seeded start state (test infrastructure)
     rng = np.random.RandomState(0)
-    acts = np.stack([rng.randint(0, c.n_acc, size=(E, N)), rng.randint(0, c.n_turn, size=(E, N))], 2).astype(np.int32)
-    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    lib.wdo_tc_step.restype = None
-
-    def tick():
-        lib.wdo_tc_step(ctypes.byref(c), P(st["loc_x"]), P(st["loc_y"]), P(st["speed"]), P(st["direction"]),
-                        P(st["acceleration"]), P(orc.agent_types), P(st["edge_pen"]), P(orc.acceleration_actions),
-                        P(orc.turn_actions), P(orc.skill_levels), P(st["sig"]), P(obs), P(acts), P(rew),
-                        P(orc.step_rewards), P(st["num_runners"]), P(st["done"]), P(st["timestep"]),
-                        ctypes.c_int(cores))
-
-    tick()  # warm-up + calibration
+    na, nt = len(orc.acceleration_actions), len(orc.turn_actions)
+    acts = np.stack([rng.randint(0, na, size=(E, orc.N)), rng.randint(0, nt, size=(E, orc.N))], 2).astype(np.int32)
+    orc.step(acts)  # warm-up + calibration
     t0 = time.perf_counter()
-    tick()
+    orc.step(acts)
     per_tick = max(time.perf_counter() - t0, 1e-6)
     ticks = int(max(3, min(400, target_seconds / per_tick)))
     t0 = time.perf_counter()
     for _ in range(ticks):
-        tick()
+        orc.step(acts)
     dt = time.perf_counter() - t0
     return {"value": E * ticks / dt, "unit": "env_steps/s", "cores": cores, "kind": "port",
-            "sample": f"{E} replicas x {ticks} ticks of the same TagContinuous 5x100 K=10 step "
-                      f"(C restatement of the reference CPU step, OpenMP over replicas, {dt:.1f} s)"}
+            "sample": f"{E} replicas x {ticks} ticks of the same TagContinuous 5x100 K=10 step from the start of an "
+                      f"episode, no resets (C restatement of the reference CPU step, OpenMP over replicas, {dt:.1f} s)"}
 
 
 def main():
@@ -134,6 +152,9 @@ def main():
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="Cartpole only: env ticks fused into one launch (fixed-policy rollout; SURVEY 8(d) "
                          "asks the ceiling run to fuse T ticks); a bench 'step' is then one launch = T ticks")
+    ap.add_argument("--no-spread", action="store_true", help="skip the four extra repeats of the timed region")
+    ap.add_argument("--profile-episodes", type=int, default=0,
+                    help="profiler helper: run this many whole episodes of ticks and exit (no timing, no JSON)")
     ap.add_argument("--unfused", action="store_true",
                     help="tick = 4 launches (sample x2, step, fused reset) instead of the single tick kernel")
     args = ap.parse_args()
@@ -199,36 +220,92 @@ def main():
         warmup = max(10, warmup // 10 * 10)
 
     def run(n):
+        if n <= 0:
+            return
         engine.run(n) if args.mode == "plan" else engine.run_graph(n, 10)
 
     barrier = wdd.barrier
+    T = int(cfg["episode_length"])
+    is_tc = args.workload == "tag_continuous"
+    if args.profile_episodes:
+        # profiler runs (scripts/collect_profiles.sh, scripts/pmc_mix_tc.sh): whole episodes and nothing
+        # else, so that a per-dispatch average over the run is the episode average
+        engine.run(args.profile_episodes * T)
+        torch.cuda.synchronize()
+        wdd.shutdown()
+        return
 
     # hipGraph capture is not allowed on the legacy default stream: use a side stream there
     side = torch.cuda.Stream() if args.mode == "graph" else None
     if side is not None:
         torch.cuda.set_stream(side)
+    ticks_done = 0  # launches since the reset (= the episode tick of every replica, mod T)
     run(warmup)
+    ticks_done += warmup
     barrier()
 
-    def time_kernel(launches=512):
-        """average launch duration of the dominant kernel: HIP events on the launch stream around
-        groups of 8 back-to-back launches (outside the timed region)"""
-        engine.plan.enable_timing(engine.step_entry, 8, max(1, launches // 8))
-        engine.run(launches)
+    WIN = 25
+
+    def time_episode(launches):
+        """per-window average launch duration (us) of the dominant kernel over `launches` back-to-back
+        launches: HIP events on the launch stream around windows of WIN launches (outside the timed region)"""
+        if len(engine.entry_names) > 1:  # unfused tick: the plan times its step entry itself
+            engine.plan.enable_timing(engine.step_entry, 8, max(1, launches // 8))
+            engine.run(launches)
+            torch.cuda.synchronize()
+            ms, n = engine.plan.read_timing()
+            engine.plan.enable_timing(-1, 1, 1)
+            return [ms / max(n, 1) * 1e3] * max(1, launches // WIN)
+        evs = []
+        for _ in range(launches // WIN):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            engine.run(WIN)
+            e1.record()
+            evs.append((e0, e1))
         torch.cuda.synchronize()
-        ms, n = engine.plan.read_timing()
-        engine.plan.enable_timing(-1, 1, 1)
-        return ms, n
+        return [e0.elapsed_time(e1) * 1e3 / WIN for e0, e1 in evs]
 
-    kern_ms, kern_n = time_kernel()   # also leaves the clocks where a long run has them
-    barrier()
-    t0 = time.perf_counter()
-    run(steps)                        # the timed region: K launches, no event records
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = wdd.max_over_ranks(elapsed)
-    ms2, n2 = time_kernel()
-    kern_ms, kern_n = kern_ms + ms2, kern_n + n2
+    P = (max(T, 500) + WIN - 1) // WIN * WIN if args.mode == "plan" else 500
+    first_pass_tick = ticks_done % T
+    win_us = time_episode(P)   # one whole episode; also leaves the clocks where a long run has them
+    ticks_done += P
+    # the timed window: on an episode boundary when it covers whole episodes, else centred mid-episode
+    t0 = 0 if steps >= T else (T - steps) // 2
+    if is_tc and args.mode == "plan":
+        pre = (t0 - ticks_done) % T
+        run(pre)
+        ticks_done += pre
+
+    def timed_region():
+        barrier()
+        t_start = time.perf_counter()
+        run(steps)                    # the timed region: K launches, no event records
+        torch.cuda.synchronize()
+        dt_local = time.perf_counter() - t_start   # this rank's own time (before it waits for the others)
+        barrier()
+        return wdd.max_over_ranks(time.perf_counter() - t_start), dt_local
+
+    window_first_tick = ticks_done % T
+    live_first = None
+    if is_tc:
+        torch.cuda.synchronize()
+        live_first = float(w.cuda_data_manager.pull_data_from_device("still_in_the_game").sum(axis=1).mean())
+    elapsed, elapsed_local = timed_region()
+    ticks_done += steps
+    repeats = [elapsed]
+    for _ in range(0 if args.no_spread else 4):  # the same K launches at the same place of the episode
+        pre = (window_first_tick - ticks_done) % T if is_tc else 0
+        run(pre)
+        ticks_done += pre
+        repeats.append(timed_region()[0])
+        ticks_done += steps
+    per_rank_ms = wdd.gather_floats(elapsed_local / steps * 1e3)
+    allreduce_us = wdd.time_allreduce(190550, 50) if world > 1 else None  # both policies' gradients, one bucket
+    second_pass_tick = ticks_done % T
+    win_us2 = time_episode(P)
+    kern_us = (sum(win_us) + sum(win_us2)) / (len(win_us) + len(win_us2))
+    kern_n = (len(win_us) + len(win_us2)) * WIN
 
     if rank == 0:
         N = w.n_agents
@@ -250,7 +327,7 @@ def main():
         # A launch that fuses T ticks (Cartpole, fixed policy) rewrites the SAME addresses every tick: only
         # one tick's worth of bytes can reach memory, so that is what the roofline is priced on
         bytes_per_launch = bytes_per_env_step * E
-        kern_s = kern_ms / max(kern_n, 1) * 1e-3
+        kern_s = kern_us * 1e-6
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they
         # were collected on exactly the code object loaded now and at this shape, else null
@@ -289,15 +366,30 @@ def main():
                 "num_envs_per_gpu": E, "num_agents": N, "launch_mode": args.mode,
                 "kernels_per_tick": len(engine.entry_names), "ticks_per_launch": engine.ticks_per_launch,
                 "parallelism": f"env-replica sharding x{world}", "sampler_seeds": seeds,
+                "episode_window": {"first_tick": window_first_tick, "last_tick": (window_first_tick + steps - 1) % T,
+                                   "episode_length": T, "whole_episodes": steps // T,
+                                   "agents_in_the_game_at_first_tick": live_first},
             },
+            "ms_per_step_spread": {"min": min(repeats) / steps * 1e3, "median": sorted(repeats)[len(repeats) // 2] / steps * 1e3,
+                                   "max": max(repeats) / steps * 1e3, "repeats": len(repeats)},
+            "per_rank_ms_per_step": per_rank_ms,
+            "allreduce_us": allreduce_us,
             "roofline": {
                 "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_us": kern_s * 1e6,
                 "samples": kern_n,
-                "timing": "HIP events around groups of 8 back-to-back launches, 512 launches before + 512 "
-                          "after the timed region",
+                "timing": f"HIP events around windows of {WIN} back-to-back launches, one whole episode "
+                          f"({P} launches) before + one after the timed region",
             },
+            # tick cost along the episode, from the two timing passes (all replicas are at the same tick)
+            "episode": {"window_ticks": WIN, "first_pass_starts_at_tick": first_pass_tick,
+                        "second_pass_starts_at_tick": second_pass_tick,
+                        "us_per_tick_mean": kern_us, "us_per_tick_min": min(win_us + win_us2),
+                        "us_per_tick_max": max(win_us + win_us2),
+                        "us_per_tick_windows_first_pass": [round(v, 2) for v in win_us]},
+            "roofline_valu": valu_roofline(engine.step_kernel_name, E, bool(args.full_obs), kern_us)
+            if is_tc else None,
         }
         if not args.no_cpu_baseline and args.workload == "tag_continuous" and world == 1:  # N = 1 only
             try:

@@ -21,14 +21,15 @@ for E in $ENVS; do
   for mode in "" "--unfused"; do
     [ -n "$mode" ] && [ "$E" != "2000" ] && continue
     d=/tmp/prof_kt_$E${mode:+_unfused}; rm -rf $d
-    rocprofv3 --kernel-trace --stats -d $d -o kt -- python $R/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --num-envs $E $mode > $O/${TAG}_bench_E$E${mode:+_unfused}.json 2>/dev/null
-    echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --num-envs $E $mode" >> $S
+    rocprofv3 --kernel-trace --stats -d $d -o kt -- python $R/bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-spread --num-envs $E $mode > $O/${TAG}_bench_E$E${mode:+_unfused}.json 2>/dev/null
+    echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-spread --num-envs $E $mode   (2000 launches + pre-roll: whole episodes, so the average is the episode average)" >> $S
     python $R/scripts/rocpd_summary.py kernel $(find $d -name "*.db" | head -1) >> $S
     echo >> $S
     for c in FETCH_SIZE WRITE_SIZE; do
       d=/tmp/prof_${c}_$E${mode:+_unfused}; rm -rf $d
-      rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --num-envs $E $mode > /dev/null 2>&1
-      echo "# rocprofv3 --kernel-trace --pmc $c -- python bench.py --steps 40 --warmup 10 --no-cpu-baseline --num-envs $E $mode" >> $P
+      if [ -z "$mode" ]; then PA="--profile-episodes 1"; else PA="--steps 40 --warmup 10 --no-cpu-baseline --no-spread"; fi
+      rocprofv3 --kernel-trace --pmc $c -d $d -o pmc -- python $R/bench.py $PA --num-envs $E $mode > /dev/null 2>&1
+      echo "# rocprofv3 --kernel-trace --pmc $c -- python bench.py $PA --num-envs $E $mode   (fused tick: one whole episode, the average is the episode average)" >> $P
       python $R/scripts/rocpd_summary.py pmc $(find $d -name "*.db" | head -1) $c >> $P
       cp $(find $d -name "*.db" | head -1) /tmp/last_$c.db
     done

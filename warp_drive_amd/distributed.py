@@ -90,6 +90,45 @@ def gather_ints(value):
     return [int(v) for v in out]
 
 
+def gather_floats(value):
+    """[value of rank 0, value of rank 1, ...] on every rank (a skewed rank shows in one line)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, float(value))
+    return [float(v) for v in out]
+
+
+def time_allreduce(n_floats, repeats=50):
+    """Median time (us) of one all-reduce of `n_floats` float32 -- the size of the trainer's flattened
+    gradient bucket -- over the job's process group (RCCL over xGMI on a GPU node); None without a group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    on_gpu = dist.get_backend() == "nccl"
+    buf = torch.zeros(int(n_floats), dtype=torch.float32, device="cuda" if on_gpu else "cpu")
+    for _ in range(5):
+        dist.all_reduce(buf)
+    times = []
+    if on_gpu:
+        torch.cuda.synchronize()
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(buf)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3)
+    else:
+        import time
+
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            dist.all_reduce(buf)
+            times.append((time.perf_counter() - t0) * 1e6)
+    times.sort()
+    return times[len(times) // 2]
+
+
 def aggregate_throughput(units_this_rank, seconds_this_rank):
     """Whole-job throughput: all ranks' units / the slowest rank's time."""
     return sum_over_ranks(units_this_rank) / max_over_ranks(seconds_this_rank)
