@@ -1,23 +1,25 @@
-"""Trainer rollout at configs[2] (2000 replicas, 50-tick batches): eager vs hipGraph replay, float32 vs
-bf16-autocast policy forward; and one training iteration end to end.  Run on the GPU box."""
-import sys, time, torch
-sys.path.insert(0, '.')
+"""Trainer at configs[2] (2000 replicas, 50-tick batches = 100 000 env-steps per iteration): the rollout
+(policy forward + fused env tick + bookkeeping) and one whole training iteration, float32 (reference
+semantics) vs bf16-autocast update.  Run on the GPU box; the output is kept as profiles/r03_rollout_timing.txt."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from warp_drive_amd.training.scripts.train import setup_trainer
-for graph, dtype, fused in ((False, "float32", True), (True, "float32", True), (True, "float32", False),
-                            (True, "bfloat16", False)):
-    ov = {"trainer": {"num_envs": 2000, "train_batch_size": 100000, "graph_rollout": graph, "rollout_dtype": dtype,
+for update, rollout, fused in (("float32", "float32", True), ("bfloat16", "float32", True), ("bfloat16", "bfloat16", False)):
+    ov = {"trainer": {"num_envs": 2000, "train_batch_size": 100000, "rollout_dtype": rollout, "update_dtype": update,
                       "fused_policy_forward": fused}}
-    tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt{int(graph)}{dtype}{int(fused)}", verbose=False)
+    tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt_{update}_{rollout}_{int(fused)}", verbose=False)
     tr._generate_rollout_batch(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): tr._generate_rollout_batch()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    tr.train(1); torch.cuda.synchronize()
+    tr.train(2); torch.cuda.synchronize()
+    s0 = tr.perf_stats; r0, u0 = s0.rollout_time, s0.training_time
     t0 = time.perf_counter()
-    tr.train(2)
+    tr.train(4)
     torch.cuda.synchronize()
-    it = (time.perf_counter() - t0) / 2
-    print(f"graph={graph} rollout_dtype={dtype} fused_policy_forward={fused}: rollout of {tr.batch_len} ticks = {dt*1e3:.1f} ms -> {dt/tr.batch_len*1e3:.3f} ms/tick, "
-          f"{tr.train_batch_size/dt:.3e} env-steps/s; training iteration {it*1e3:.0f} ms -> {tr.train_batch_size/it:.3e} env-steps/s end to end")
+    it = (time.perf_counter() - t0) / 4
+    print(f"update_dtype={update} rollout_dtype={rollout} fused_policy_forward={fused}: rollout of {tr.batch_len} ticks = {dt*1e3:.1f} ms "
+          f"-> {dt/tr.batch_len*1e3:.3f} ms/tick, {tr.train_batch_size/dt:.3e} env-steps/s; training iteration {it*1e3:.0f} ms "
+          f"(rollout {(s0.rollout_time - r0)/4*1e3:.0f} + update {(s0.training_time - u0)/4*1e3:.0f}) -> {tr.train_batch_size/it:.3e} env-steps/s end to end")
     tr.graceful_close()

@@ -2,7 +2,9 @@
 rendezvousing over gloo (RCCL refuses two ranks on one GPU).  Exercises what round 1 never started:
 a rank > 0 constructing EnvWrapper without an event messenger (reference protocol:
 warp_drive/training/utils/device_child_process/child_process_base.py:36-85,
-pycuda_function_manager.py:170-181), bench.py launching its own ranks, and the 2-rank DDP trainer."""
+pycuda_function_manager.py:170-181), bench.py launching its own ranks, and the 2-rank trainer (one
+gradient bucket, one all-reduce per iteration).  The last test runs the same over RCCL when the box has
+two GPUs."""
 import json
 import os
 import subprocess
@@ -67,7 +69,7 @@ def test_train_two_ranks(tmp_path):
         assert path.exists(), os.listdir(tmp_path)
         recs.append([json.loads(l) for l in open(path)])
     assert recs[0][-1]["Iterations Completed"] == 2 and recs[1][-1]["Iterations Completed"] == 2
-    # DDP keeps the replicas' models identical: rank 0 saves, and the ranks' losses differ (own replicas)
+    # the shared gradient bucket keeps the replicas' models identical: rank 0 saves, the ranks' losses differ (own replicas)
     assert any(f.endswith(".state_dict") for f in os.listdir(tmp_path))
 
 
@@ -112,3 +114,35 @@ def test_rccl_backend_loads_and_reduces(tmp_path):
     assert p.exitcode == 0, f"RCCL worker exit code {p.exitcode}"
     backend, ok, total = open(out).read().split()
     assert backend == "nccl" and ok == "1" and float(total) == 28.0
+
+
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus(tmp_path):
+    """The real N > 1 path: one rank per GPU over RCCL (WD_DIST_BACKEND / WD_FORCE_DEVICE unset).  Needs two
+    visible GPUs -- RCCL refuses two ranks on one device -- and skips with the reason otherwise, so that a
+    multi-GPU lease exercises it inside the GPU test tier."""
+    import torch
+
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: RCCL with world_size 2 needs two devices (the 1-GPU variants above use gloo)")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "WD_FORCE_DEVICE", "WD_DIST_BACKEND"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["allreduce_us"] > 0
+    assert d["config"]["sampler_seeds"] == [274880, 274881]
+    from warp_drive_amd.training.scripts import launch
+
+    cmd = launch.build_command("tag_gridworld", 2, launch.free_port(),
+                               ["--iters", "2", "--num_envs", "40", "--train_batch_size", "400",
+                                "--results_dir", str(tmp_path)])
+    out = subprocess.run(cmd, capture_output=True, text=True, env=launch.child_environment(env), cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert (tmp_path / "results_device_0.json").exists() and (tmp_path / "results_device_1.json").exists()

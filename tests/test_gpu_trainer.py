@@ -75,6 +75,30 @@ def test_train_gridworld_and_cartpole(tmp_path):
     _train("single_cartpole", ov2, tmp_path / "cp")
 
 
+def test_update_in_bf16_and_downsampling_keys(tmp_path):
+    """`trainer.update_dtype: bfloat16` runs the update's GEMMs under autocast (float32 master weights, loss and
+    optimizer): it must train, and its first loss must agree with the float32 update of the same batch to the
+    stated tolerance (5e-2 relative on the total loss: bf16 keeps 8 mantissa bits through two 256-wide
+    layers).  `trainer.neg_pos_env_ratio` reaches the objective (trainer_base.py:210): the two counters of
+    a2c.py:196-220 are logged."""
+    losses = {}
+    for dt in ("float32", "bfloat16"):
+        ov = {"trainer": {"num_envs": 32, "train_batch_size": 32 * 10, "num_episodes": 100, "update_dtype": dt,
+                          "neg_pos_env_ratio": 1, "seed": 7},
+              "env": {"num_runners": 20, "episode_length": 30, "num_other_agents_observed": 6},
+              "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
+        torch.manual_seed(1234)  # the same initial weights in both runs (the rollouts are seeded by the config)
+        trainer, metrics = _train("tag_continuous", ov, tmp_path / dt, iters=1)
+        assert trainer.neg_pos_env_ratio == 1
+        for pol in ("runner", "tagger"):
+            assert "Num of Positive Sampled Envs" in metrics[pol] and "Num of Negative Sampled Envs" in metrics[pol]
+        assert trainer.grad_bucket is not None and trainer.grad_bucket.attached()
+        losses[dt] = {pol: metrics[pol]["Total loss"] for pol in metrics}
+    for pol in losses["float32"]:
+        a, b = losses["float32"][pol], losses["bfloat16"][pol]
+        assert abs(a - b) <= 5e-2 * max(abs(a), 1e-3), (pol, a, b)
+
+
 def test_graph_and_eager_rollouts_agree(tmp_path):
     """the hipGraph replay of a rollout tick must produce exactly what the eager tick produces"""
     from tests.hip_harness import require_gpu

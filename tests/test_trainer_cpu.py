@@ -130,6 +130,57 @@ def test_ddp_gradient_allreduce_two_ranks(tmp_path):
     np.testing.assert_array_equal(w0, w1)  # different data, identical parameters after the step
 
 
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from warp_drive_amd import distributed as wdd
+    from warp_drive_amd.training.grad_bucket import GradientBucket
+
+    wdd.init_process_group(backend="gloo")
+    torch.manual_seed(10 + rank)  # DIFFERENT initial weights per rank: the bucket broadcasts rank 0's
+    models = [FullyConnected(7, [3, 4], [8]), FullyConnected(5, [2], [6, 6])]  # two policies, one bucket
+    bucket = GradientBucket(models)
+    bucket.broadcast_parameters(src=0)
+    opts = [torch.optim.SGD(m.parameters(), lr=0.1) for m in models]
+    algo = A2C(discount_factor_gamma=0.9, vf_loss_coeff=1.0, entropy_coeff=0.01)
+    for it in range(2):  # two iterations: the views must survive an optimizer step
+        bucket.zero()
+        for k, (m, obs_dim, heads) in enumerate(zip(models, (7, 5), ((3, 4), (2,)))):
+            g = torch.Generator().manual_seed(1000 * it + 100 * k + rank)  # every rank rolls out its OWN replicas
+            obs = torch.randn(4, 5, 2, obs_dim, generator=g)
+            actions = torch.stack([torch.randint(0, a, (4, 5, 2), generator=g) for a in heads], dim=-1)
+            rewards = torch.randn(4, 5, 2, generator=g)
+            probs, vals = m(obs)
+            loss, _ = algo.compute_loss_and_metrics(timestep=0, actions_batch=actions, rewards_batch=rewards,
+                                                    done_flags_batch=torch.zeros(4, 5, dtype=torch.int32),
+                                                    action_probabilities_batch=probs, value_functions_batch=vals)
+            loss.backward()
+        local = bucket.flat.clone()
+        bucket.all_reduce_mean()
+        assert bucket.attached()
+        np.save(os.path.join(out_dir, f"local_{it}_{rank}.npy"), local.numpy())
+        np.save(os.path.join(out_dir, f"avg_{it}_{rank}.npy"), bucket.flat.numpy())
+        for o in opts:
+            o.step()
+    flat = torch.cat([p.detach().reshape(-1) for m in models for p in m.parameters()])
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), flat.numpy())
+    open(os.path.join(out_dir, f"n_{rank}.txt"), "w").write(str(bucket.collectives))
+    wdd.shutdown()
+
+
+def test_gradient_bucket_one_allreduce_for_all_policies(tmp_path):
+    """both policies' gradients are ONE flat buffer and ONE all-reduce per iteration (the
+    reference wraps each policy in its own DDP, trainer_a2c.py:137-146)."""
+    mp.spawn(_bucket_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "n_0.txt").read() == "2" and open(tmp_path / "n_1.txt").read() == "2"  # 2 iterations
+    for it in range(2):
+        l0, l1 = np.load(tmp_path / f"local_{it}_0.npy"), np.load(tmp_path / f"local_{it}_1.npy")
+        assert np.abs(l0 - l1).max() > 1e-4  # different replicas, different local gradients ...
+        for r in range(2):                    # ... the same average on both ranks
+            np.testing.assert_allclose(np.load(tmp_path / f"avg_{it}_{r}.npy"), 0.5 * (l0 + l1), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(np.load(tmp_path / "w_0.npy"), np.load(tmp_path / "w_1.npy"))
+
+
 def test_launcher_command_line(capsys):
     """f2: the launcher starts one rank per GPU through torch.distributed.run on localhost"""
     from warp_drive_amd.training.scripts import launch

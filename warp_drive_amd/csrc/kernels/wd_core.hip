@@ -52,7 +52,11 @@ __global__ void free_random() {}
 // reference's [E, n, 1] per-head array; (n_heads, k) writes head k straight into the
 // combined [E, n, n_heads] action tensor, replacing the strided torch copy of
 // trainer_base.py:506-512.
-// Dynamic LDS: blockDim.x * lds_stride floats (lds_stride odd => conflict-free rows).
+// Dynamic LDS: blockDim.x * lds_stride floats (lds_stride odd => conflict-free rows) PLUS 128 bytes:
+// rows of at most WD_SLAB_CH (24) entries are read back 24 entries at a time from the row start
+// (wd_slab_sample; the entries past the row length are masked off), so the last row's read runs up to
+// 92 bytes past the slab.  HIPSampler.categorical_launch adds the padding; any other launcher (C-ABI
+// users) must do the same.
 __global__ void sample_actions(uint32_t *rng_state, const float *__restrict__ distr,
                                int *__restrict__ action_indices, float *cum_distr, int n_rows,
                                int num_actions, int use_argmax, int lds_stride, int stream_tag,

@@ -38,14 +38,44 @@ class FullyConnected(nn.Module):
         self.policy_head = nn.ModuleList([nn.Linear(dims[-1], int(a)) for a in head_sizes])
         self.vf_head = nn.Linear(dims[-1], 1)
         self.head_sizes = [int(a) for a in head_sizes]
+        self._inference_cache = {}  # dtype -> (trunk [(w, b)], concatenated head (w, b)); see refresh_inference_cache
+
+    def refresh_inference_cache(self):
+        """forget the cast / concatenated copies of the weights that forward_inference keeps (call after every
+        optimizer step or checkpoint load, as FusedPolicyForward.pack() is)"""
+        self._inference_cache = {}
+
+    @torch.no_grad()
+    def _inference_weights(self, dtype):
+        # keyed by the parameters' version counters too: an in-place update (optimizer step, checkpoint
+        # load) that nobody announced still invalidates the copies
+        key = (dtype, tuple(p._version for p in self.parameters()))
+        if key not in self._inference_cache:
+            self._inference_cache = {}
+            cast = (lambda t: t.detach()) if dtype is None else (lambda t: t.detach().to(dtype))
+            trunk = [(cast(self.fc[str(i)][0].weight), cast(self.fc[str(i)][0].bias)) for i in range(len(self.fc))]
+            w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
+            b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
+            self._inference_cache[key] = (trunk, (cast(w), cast(b)))
+        return self._inference_cache[key]
 
     def forward(self, obs):
-        """obs [..., obs_size] -> ([probs per head, each [..., A_h]], values [...])"""
+        """obs [..., obs_size] -> ([probs per head, each [..., A_h]], values [...]).
+        The layers run through `_Affine` (bias + ReLU in the GEMM epilogue; a backward without reduction
+        kernels over the ~1e7 rows of a training batch) and all heads through ONE GEMM over the
+        concatenated head weights, like forward_inference; parameters and their names are nn.Linear's."""
         x = obs
         for i in range(len(self.fc)):
-            x = self.fc[str(i)](x)
-        probs = [torch.softmax(head(x), dim=-1) for head in self.policy_head]
-        return probs, self.vf_head(x)[..., 0]
+            lin = self.fc[str(i)][0]
+            x = _Affine.apply(x, lin.weight, lin.bias, True)
+        w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
+        b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
+        out = _Affine.apply(x, w, b, False)
+        probs, start = [], 0
+        for a in self.head_sizes:
+            probs.append(torch.softmax(out[..., start:start + a], dim=-1))
+            start += a
+        return probs, out[..., start]
 
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
@@ -58,14 +88,9 @@ class FullyConnected(nn.Module):
         x = obs.reshape(-1, obs.shape[-1])
         if dtype is not None:
             x = x.to(dtype)
-        for i in range(len(self.fc)):
-            lin = self.fc[str(i)][0]
-            w, b = (lin.weight, lin.bias) if dtype is None else (lin.weight.to(dtype), lin.bias.to(dtype))
-            x = _linear_relu(x, w, b)
-        w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
-        b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        if dtype is not None:
-            w, b = w.to(dtype), b.to(dtype)
+        trunk, (w, b) = self._inference_weights(dtype)  # cast / concatenated once per optimizer step
+        for wi, bi in trunk:
+            x = _linear_relu(x, wi, bi)
         out = torch.nn.functional.linear(x, w, b).float()
         probs, start = [], 0
         for a in self.head_sizes:
@@ -74,12 +99,78 @@ class FullyConnected(nn.Module):
         return probs, out[:, start].reshape(*lead)
 
 
+def _column_sums(g):
+    """float32 column sums of a [rows, features] gradient with ~1e7 rows.  A plain `g.sum(0)` launches 512
+    blocks for the whole tensor (38 ms per 256-wide layer on MI355X) and a GEMM with a row of ones is as
+    slow (a 1 x rows x features GEMM): two stages -- [R, rows / R, features] summed over the middle
+    dimension (R x features independent outputs: the chip is full and the reads are coalesced), then
+    over R."""
+    rows = g.shape[0]
+    for r in (2000, 2048, 1024, 1000, 800, 512, 500, 400, 256, 250, 200, 128, 100, 64):
+        if rows % r == 0 and rows // r >= 16:
+            return g.view(r, rows // r, g.shape[1]).sum(dim=1, dtype=torch.float32).sum(dim=0)
+    return g.sum(dim=0, dtype=torch.float32)
+
+
+def _weight_grad(g, x):
+    """g^T @ x for [rows, out] x [rows, in] with ~1e7 rows: one GEMM whose contraction is 1e7 long and
+    whose result is 256 x 256 leaves most of the chip idle (5-10 ms at 1 TB/s on MI355X); as a batch of
+    S independent slices of the rows followed by a sum over S it streams both operands at memory speed."""
+    rows = g.shape[0]
+    if rows >= (1 << 20):
+        for sl in (250, 256, 200, 128, 125, 100, 64, 50, 32):
+            if rows % sl == 0:
+                part = torch.bmm(g.view(sl, rows // sl, g.shape[1]).transpose(1, 2), x.view(sl, rows // sl, x.shape[1]))
+                return part.sum(dim=0, dtype=torch.float32)
+    return (g.t() @ x).float()
+
+
+class _Affine(torch.autograd.Function):
+    """y = [relu](x @ W^T + b) over the last dimension of x.
+
+    Why not nn.Linear + nn.ReLU: a training batch of configs[2] is ~1e7 rows, and autograd's bias gradient
+    is a column reduction of the [rows, features] gradient that PyTorch runs with 512 blocks -- 38 ms per
+    256-wide layer on MI355X, 37 % of the whole update (profiles/r03_update_kernels.txt).  Here the bias
+    gradient is a two-stage sum that fills the chip (`_column_sums`),
+    bias + ReLU ride in the forward GEMM's epilogue, the ReLU mask is applied in one pass, and the input
+    gradient is skipped where nobody needs it (the first layer).  Under autocast the GEMMs run in the
+    autocast dtype (bf16 matrix cores) with float32 parameters and float32 parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        dev = x.device.type
+        dt = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
+        x2 = x.reshape(-1, x.shape[-1]).to(dt)
+        wc, bc = w.to(dt), b.to(dt)
+        with torch.autocast(device_type=dev, enabled=False):
+            y = _linear_relu(x2, wc, bc) if relu else torch.addmm(bc, x2, wc.t())
+        ctx.save_for_backward(x2, wc, y if relu else x2.new_empty(0))
+        ctx.relu, ctx.in_shape = bool(relu), x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wc, y = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).to(x2.dtype)
+        if ctx.relu:
+            g2 = torch.ops.aten.threshold_backward(g2, y, 0)
+        with torch.autocast(device_type=g.device.type, enabled=False):
+            gx = (g2 @ wc).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
+            gw = _weight_grad(g2, x2)
+            gb = _column_sums(g2)
+        return gx, gw, gb, None
+
+
+_FUSED_EPILOGUE = {"ok": hasattr(torch, "_addmm_activation")}  # decided once: a private torch entry point
+
+
 def _linear_relu(x, weight, bias):
     """relu(x @ weight.T + bias), with the bias + ReLU epilogue fused into the GEMM where the backend
-    offers it (CUDA/ROCm tensors); plain Linear + ReLU otherwise."""
-    if x.is_cuda and hasattr(torch, "_addmm_activation"):
+    offers it (CUDA/ROCm tensors); plain Linear + ReLU otherwise.  `torch._addmm_activation` is private:
+    any failure (signature / dtype support changed) switches to the plain form for the rest of the run."""
+    if x.is_cuda and _FUSED_EPILOGUE["ok"]:
         try:
             return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
-        except RuntimeError:
-            pass
+        except Exception:  # noqa: BLE001 -- TypeError / NotImplementedError / RuntimeError alike
+            _FUSED_EPILOGUE["ok"] = False
     return torch.relu(torch.nn.functional.linear(x, weight, bias))

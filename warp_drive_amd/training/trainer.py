@@ -11,8 +11,9 @@ host: the reference pulls `done_flags.any()` to the host and synchronises three 
 
 and the only host round trips are the optional metric reads every `metrics_log_freq`
 iterations.  Multi-GPU: one process per GPU, each with its own replicas and seed + rank; the
-models are wrapped in DistributedDataParallel (backend "nccl" = RCCL over xGMI), so the only
-collective is the bucketed gradient all-reduce (trainer_a2c.py:137-146).
+gradients of ALL policies live in one flat bucket (training/grad_bucket.py) that is averaged over the
+ranks with a single all-reduce per training iteration (backend "nccl" = RCCL over xGMI) -- the
+reference wraps every policy in its own DistributedDataParallel (trainer_a2c.py:137-146).
 """
 import json
 import logging
@@ -27,6 +28,7 @@ from warp_drive_amd import distributed as wdd
 from warp_drive_amd.managers.function_manager import HIPSampler
 from warp_drive_amd.rollout import RolloutEngine
 from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
 from warp_drive_amd.training.policy_kernel import FusedPolicyForward
@@ -142,8 +144,6 @@ class Trainer:
             ckpt = pcfg["model"].get("model_ckpt_filepath", "")
             if ckpt:
                 self.load_model_checkpoint({pol: ckpt}, models={pol: model})
-            if self.world > 1 and torch.distributed.is_initialized():
-                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device_id])
             self.models[pol] = model
             self.ids[pol] = torch.tensor(ids, dtype=torch.long, device=self.device)
             self.optimizers[pol] = torch.optim.Adam(model.parameters(), lr=pcfg["lr"])
@@ -157,6 +157,16 @@ class Trainer:
                 self.trainers[pol] = PPO(clip_param=pcfg["clip_param"], **common)
             else:
                 raise NotImplementedError(f"algorithm {algo}: only A2C and PPO are supported")
+        # one flat gradient bucket over the trainable policies: one all-reduce per iteration at N > 1
+        trainable = [self.models[p] for p in self.policies if config["policy"][p]["to_train"]]
+        self.grad_bucket = GradientBucket(trainable, self.device) if trainable else None
+        if self.grad_bucket is not None:
+            self.grad_bucket.broadcast_parameters(src=0)
+        # positive / negative replica down-sampling of the objectives (trainer_base.py:210, a2c.py:196-220)
+        self.neg_pos_env_ratio = tcfg.get("neg_pos_env_ratio", -1)
+        # precision of the UPDATE's GEMMs: "float32" (reference semantics) or "bfloat16" (autocast: bf16
+        # matrix cores, float32 master weights, float32 softmax / loss / optimizer)
+        self._update_dtype = {"float32": None, "bfloat16": torch.bfloat16}[str(tcfg.get("update_dtype", "float32"))]
         self.batch = {
             pol: {
                 "obs": dm.data_on_device_via_torch(f"{Constants.PROCESSED_OBSERVATIONS}_batch_{pol}")
@@ -196,8 +206,7 @@ class Trainer:
 
     # --------------------------------------------------------------------------- rollout
     def _inference_model(self, pol):
-        m = self.models[pol]
-        return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+        return self.models[pol]
 
     def _rollout_forward(self, pol, obs_p):
         """policy forward of the rollout: probabilities per head, float32"""
@@ -280,30 +289,39 @@ class Trainer:
     def _update_model_params(self, iteration, log):
         metrics = {}
         done = self.done_batch
-        for pol in self.policies:
-            pcfg = self.config["policy"][pol]
-            if not pcfg["to_train"]:
-                continue
+        trained = [pol for pol in self.policies if self.config["policy"][pol]["to_train"]]
+        if not trained:
+            return metrics
+        self.grad_bucket.zero()  # (the .grad views stay attached to the bucket: no zero_grad(set_to_none))
+        for pol in trained:
             batch = self.batch[pol]
-            probs, values = self.models[pol](batch["obs"][: self.batch_len])
+            with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
+                                enabled=self._update_dtype is not None):
+                probs, values = self.models[pol](batch["obs"][: self.batch_len])
+            probs, values = [p.float() for p in probs], values.float()
             loss, m = self.trainers[pol].compute_loss_and_metrics(
                 timestep=self.current_timestep[pol], actions_batch=batch["actions"].long(),
                 rewards_batch=batch["rewards"], done_flags_batch=done, action_probabilities_batch=probs,
-                value_functions_batch=values, perform_logging=log)
-            self.optimizers[pol].zero_grad(set_to_none=True)
-            loss.backward()  # DDP: bucketed gradient all-reduce over RCCL overlaps this backward
+                value_functions_batch=values, perform_logging=log, negative_positive_ratio=self.neg_pos_env_ratio)
+            loss.backward()  # accumulates into this policy's slice of the flat bucket
+            if log:
+                metrics[pol] = m
+        self.grad_bucket.all_reduce_mean()  # ONE collective for all policies (RCCL over xGMI at N > 1)
+        for pol in trained:
+            pcfg = self.config["policy"][pol]
             if pcfg["clip_grad_norm"]:
                 torch.nn.utils.clip_grad_norm_(self.models[pol].parameters(), pcfg["max_grad_norm"])
             self.optimizers[pol].step()
             if self._fused_forward[pol] is not None:
                 self._fused_forward[pol].pack()  # the rollout kernel reads re-packed weights
+            self.models[pol].refresh_inference_cache()
             self.current_timestep[pol] += self.train_batch_size
             if log:
+                m = metrics[pol]
                 m["Current timestep"] = self.current_timestep[pol]
                 m["Learning rate"] = pcfg["lr"]
                 cnt = float(self._ep_cnt.item())
                 m["Mean episodic reward"] = float(self._ep_sum[pol].item()) / cnt if cnt > 0 else float("nan")
-                metrics[pol] = m
         return metrics
 
     # ----------------------------------------------------------------------------- train
@@ -369,6 +387,7 @@ class Trainer:
         for pol, path in ckpts_dict.items():
             assert os.path.isfile(path), f"invalid model checkpoint path {path}"
             models[pol].load_state_dict(torch.load(path, map_location=self.device))
+            models[pol].refresh_inference_cache()
             stem = os.path.basename(path).split(".state_dict")[0]
             try:
                 self.current_timestep[pol] = int(stem.split("_")[-1])
@@ -386,6 +405,12 @@ class Trainer:
         out = {}
         for pol in self.policies:
             ids = self.ids[pol]
+            if self._fused_forward[pol] is not None:
+                # the same kernel as the training rollout, so that evaluation (use_argmax at near-ties
+                # included) picks what the rollout would pick
+                self._fused_forward[pol](flat_obs, self._ids32[pol], self.probs)
+                out[pol] = [p if len(self.policies) == 1 else p.index_select(1, ids) for p in self.probs]
+                continue
             obs_p = flat_obs if len(self.policies) == 1 else flat_obs.index_select(1, ids)
             probs = self._rollout_forward(pol, obs_p)
             out[pol] = probs
