@@ -145,6 +145,8 @@ def main():
                     help="tag_continuous = BASELINE configs[2] (the headline metric); the other two are the "
                          "configs[1] / configs[4] side workloads quoted in DESIGN.md")
     ap.add_argument("--full-obs", action="store_true", help="use_full_observation=True variant (F = 729)")
+    ap.add_argument("--num-runners", type=int, default=None, help="TagContinuous: runners per replica (default 100)")
+    ap.add_argument("--num-taggers", type=int, default=None, help="TagContinuous: taggers per replica (default 5)")
     ap.add_argument("--mode", choices=("plan", "graph"), default="plan",
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,6 +194,10 @@ def main():
 
     if args.workload == "tag_continuous":
         cfg = dict(BENCH_CFG, use_full_observation=bool(args.full_obs))
+        if args.num_runners is not None:
+            cfg["num_runners"] = args.num_runners
+        if args.num_taggers is not None:
+            cfg["num_taggers"] = args.num_taggers
         E = args.num_envs or 2000
         env_obj = TagContinuous(**cfg)
     elif args.workload == "tag_gridworld":  # BASELINE configs[1]
@@ -213,7 +219,17 @@ def main():
     seeds = wdd.gather_ints(seed)
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
-    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused)
+    rollout_batch = None
+    if args.workload == "cartpole" and args.ticks_per_launch > 1:
+        # the ceiling run: T ticks per launch, every tick recorded in the trainer's [T, E, ...] batch tensors
+        # (distinct addresses per tick: T ticks move T times the bytes)
+        Tn, dev = args.ticks_per_launch, torch.device("cuda", device)
+        rollout_batch = {"obs": torch.zeros((Tn, E, 1, 4), dtype=torch.float32, device=dev),
+                         "actions": torch.zeros((Tn, E, 1, 1), dtype=torch.int32, device=dev),
+                         "rewards": torch.zeros((Tn, E, 1), dtype=torch.float32, device=dev),
+                         "done": torch.zeros((Tn, E), dtype=torch.int32, device=dev)}
+    engine = RolloutEngine(w, sampler, probabilities=None, reset_done=not args.no_reset, fused=not args.unfused,
+                           rollout_batch=rollout_batch)
     steps, warmup = args.steps, args.warmup
     if args.mode == "graph":
         steps = max(10, steps // 10 * 10)
@@ -312,9 +328,10 @@ def main():
         if args.workload == "tag_continuous":
             K = cfg["num_other_agents_observed"]
             bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
-            label = ("BASELINE configs[2]: TagContinuous 5 taggers x 100 runners, "
-                     f"{'full obs F=729' if args.full_obs else 'partial obs K=10 (F=71)'}")
-            metric = "env steps/sec, TagContinuous 5 taggers x 100 runners"
+            shape = f"{cfg['num_taggers']} taggers x {cfg['num_runners']} runners"
+            label = (("BASELINE configs[2]: " if N == 105 else "") + f"TagContinuous {shape}, "
+                     f"{f'full obs F={7 * (N - 1) + 1}' if args.full_obs else 'partial obs K=10 (F=71)'}")
+            metric = f"env steps/sec, TagContinuous {shape}"
         elif args.workload == "tag_gridworld":
             bytes_per_env_step = 576  # N=5, full obs F=21
             label, metric = "BASELINE configs[1]: TagGridWorld 10x10, 5 agents, full obs", "env steps/sec, TagGridWorld"
@@ -324,9 +341,12 @@ def main():
         if engine.fused:
             # a fused tick kernel also reads every head's probabilities and reads+writes the RNG epoch
             bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
-        # A launch that fuses T ticks (Cartpole, fixed policy) rewrites the SAME addresses every tick: only
-        # one tick's worth of bytes can reach memory, so that is what the roofline is priced on
         bytes_per_launch = bytes_per_env_step * E
+        if rollout_batch is not None:
+            # T ticks per launch with every tick recorded: per env-step 16 B observation + 4 B action + 4 B reward +
+            # 4 B done flag written (28 B, distinct addresses), per launch and replica the state in and out, the
+            # probabilities, the RNG epoch and the time step (SURVEY 8(d)'s 68 B counted once)
+            bytes_per_launch = (28 * engine.ticks_per_launch + bytes_per_env_step) * E
         kern_s = kern_us * 1e-6
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they

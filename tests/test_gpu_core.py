@@ -431,6 +431,61 @@ def test_cartpole_fused_tick(ticks):
     assert finished >= E
 
 
+def test_cartpole_rollout_records_every_tick():
+    """The T-tick launch with the trainer's batch tensors: row k of the observation / action / reward / done
+    batches is tick k of the launch -- the observation the action was sampled on, the action (draw for draw),
+    the reward and the done flag -- replayed through the oracle; the per-tick arrays hold the last tick.
+    (trainer_base.py:392-426 records exactly these per tick.)"""
+    import torch
+    from oracle.cartpole_np import CartPoleOracle
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from tests.hip_harness import OBS, make_wrapper, pull, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+
+    require_gpu()
+    E, T, ticks = 2003, 23, 16
+    env = CUDAClassicControlCartPoleEnv(episode_length=T, seed=32145)
+    env.ticks_per_launch = ticks
+    w = make_wrapper(env, E)
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=4)
+    rng = np.random.RandomState(2)
+    probs = torch.from_numpy(rng.dirichlet(np.ones(2), size=(E, 1)).astype(np.float32)).cuda()
+    batch = {"obs": torch.full((ticks, E, 1, 4), 7.0, device="cuda"),
+             "actions": torch.full((ticks, E, 1, 1), -1, dtype=torch.int32, device="cuda"),
+             "rewards": torch.full((ticks, E, 1), -1.0, device="cuda"),
+             "done": torch.full((ticks, E), -1, dtype=torch.int32, device="cuda")}
+    engine = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch)
+    assert engine.fused and engine.ticks_per_launch == ticks
+    orc = CartPoleOracle(E, T, initial_state=pull(w, "state")[0, 0])
+    rng_words = np.zeros(4 + E, dtype=np.uint32)
+    probs_host = probs.cpu().numpy()
+    finished = 0
+    for launch in range(6):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        engine.run(1)
+        torch.cuda.synchronize()
+        b = {k: v.cpu().numpy() for k, v in batch.items()}
+        for k in range(ticks):
+            np.testing.assert_array_equal(b["obs"][k, :, 0], orc.obs, err_msg=f"obs row {k} of launch {launch}")
+            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            a = sample_actions_counting(probs_host, u.reshape(E, 1))
+            orc.step(a.reshape(E, 1, 1))
+            np.testing.assert_array_equal(b["actions"][k, :, 0, 0], a[:, 0])
+            np.testing.assert_array_equal(b["rewards"][k, :, 0], orc.rewards)
+            np.testing.assert_array_equal(b["done"][k], orc.done)
+            finished += int((orc.done > 0).sum())
+            orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)
+        np.testing.assert_array_equal(pull(w, "_timestep_"), orc.timestep)
+        np.testing.assert_array_equal(pull(w, OBS)[:, 0], orc.obs)  # finished replicas already hold the reset observation
+    assert finished >= 3 * E
+
+
 def test_consistency_checker_api():
     """The reference's own parity harness, at 1e-5 instead of 1 % (its scenarios:
     tests/example_envs/pycuda_tests/test_tag_continuous.py:15-80, test_tag_gridworld.py:13-38)."""

@@ -77,7 +77,12 @@ __global__ void HipClassicControlCartPoleEnvStep(
 // so one launch per tick is launch-bound -- SURVEY 8(d) asks the ceiling run to fuse T ticks).  The
 // policy's probabilities are read once per launch, so ticks > 1 is a fixed-policy rollout; every tick
 // still writes its action, observation, reward, done and timestep.  `_done_` reports the last tick.
-// (No __restrict__ on the arrays: the reset table aliases them.)
+// With the four `*_batch` pointers (the trainer's [T, E, ...] batch tensors, training/data_loader.py:
+// processed observations, actions, rewards, done flags) tick k of the launch writes ROW k of them --
+// the observation the policy acted on, the sampled action, the reward and the done flag, exactly what
+// trainer_base.py:392-426 records per tick -- so T ticks move T times the bytes (28 B per env-step,
+// all coalesced: the real HBM ceiling run of configs[4]); the per-tick arrays then receive the last
+// tick only.  (No __restrict__ on the arrays: the reset table aliases them.)
 __global__ void HipClassicControlCartPoleEnvTick(
     float4 *state_arr, int *action_arr, int *done_arr,
     float *reward_arr, float4 *observation_arr, float gravity,
@@ -85,7 +90,7 @@ __global__ void HipClassicControlCartPoleEnvTick(
     float tau, float theta_threshold_radians, float x_threshold,
     int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
-    int stream_tag, int ticks) {
+    int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch) {
   const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
                     theta_threshold_radians, x_threshold};
   const CpResetEntry *table = (const CpResetEntry *)reset_table;
@@ -95,25 +100,52 @@ __global__ void HipClassicControlCartPoleEnvTick(
     float4 s = state_arr[env];
     const uint32_t epoch0 = rng_state[WD_RNG_HEADER + env];
     const float *row = probs + (long)env * n_actions;
+    // The running float32 sums of the (fixed) probabilities, once per launch and in registers: a load
+    // inside the tick loop would wait for every store issued before it (the memory counters return in
+    // order) -- 2.9 us per tick at 100 000 replicas instead of 0.5.
+    constexpr int CP_MAX_REG_ACTIONS = 8;
+    float cumv[CP_MAX_REG_ACTIONS];
+    {
+      float cum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) {
+        if (i < n_actions) cum = (i == 0) ? row[0] : cum + row[i];
+        cumv[i] = cum;
+      }
+    }
     for (int k = 0; k < ticks; ++k) {
       // ---- sample (random.cu:51-85): inverse CDF on a running float32 sum
       const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, 3u}, k0, k1);
       const float u = wd_u01_open_closed(rnd.x);
-      float cum = 0.0f;
       int cnt = 0;
-      for (int i = 0; i < n_actions; ++i) {
-        cum = (i == 0) ? row[0] : cum + row[i];
-        cnt += (cum < u) ? 1 : 0;
+      if (n_actions <= CP_MAX_REG_ACTIONS) {
+#pragma unroll
+        for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) cnt += (i < n_actions && cumv[i] < u) ? 1 : 0;
+      } else {
+        float cum = 0.0f;
+        for (int i = 0; i < n_actions; ++i) {
+          cum = (i == 0) ? row[0] : cum + row[i];
+          cnt += (cum < u) ? 1 : 0;
+        }
       }
       const int a = min(cnt, n_actions - 1);
       // ---- step
+      const long brow = (long)k * n_envs + env;
+      if (obs_batch) obs_batch[brow] = s;  // the observation this action was sampled on
       t += 1;
       const bool terminated = cp_euler(s, a, p);
       const bool fin = (t == episode_length) || terminated;
-      action_arr[env] = a;
-      observation_arr[env] = s;
-      reward_arr[env] = 1.0f;
-      done_arr[env] = fin ? 1 : 0;
+      if (obs_batch) {
+        action_batch[brow] = a;
+        reward_batch[brow] = 1.0f;
+        done_batch[brow] = fin ? 1 : 0;
+      }
+      if (!obs_batch || k == ticks - 1 || fin) {
+        action_arr[env] = a;
+        observation_arr[env] = s;
+        reward_arr[env] = 1.0f;
+        done_arr[env] = fin ? 1 : 0;
+      }
       if (fin || k == ticks - 1) state_arr[env] = s;  // otherwise the state stays in registers
       // ---- reset in place (reset.cu:9-75 for every registered array); `_done_` stays set
       if (fin) {
@@ -124,6 +156,9 @@ __global__ void HipClassicControlCartPoleEnvTick(
         }
         t = 0;
         s = state_arr[env];
+        // the reload is consumed HERE, inside the rare branch: otherwise the wait for it lands at the top
+        // of the tick loop, where it also waits for every store of the previous tick
+        asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w));
       }
     }
     env_timestep_arr[env] = t;

@@ -142,10 +142,13 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
     TICK_HEADS = 1          # action heads the fused tick kernel samples (RolloutEngine)
     ticks_per_launch = 1    # > 1: fixed-policy rollout, T ticks fused per launch (the HBM-ceiling run)
 
-    def tick_launch(self, sampler, probabilities, resetter, env_range=None):
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None):
         """Fused rollout tick(s): sample + step + reset of a finished replica, `ticks_per_launch`
         times in ONE launch (HipClassicControlCartPoleEnvTick).  probabilities = [float32 CUDA tensor
-        [E, 1, n_actions]]; `_done_` reports the last tick of the launch."""
+        [E, 1, n_actions]]; `_done_` reports the last tick of the launch.  `batch` (optional) = the
+        trainer's batch tensors {"obs": [T, E, 1, 4] float32, "actions": [T, E, 1, 1] int32, "rewards":
+        [T, E, 1] float32, "done": [T, E] int32} with T >= ticks_per_launch: tick k of the launch writes
+        their row k (what trainer_base.py:392-426 records per tick)."""
         from warp_drive_amd.managers.function_manager import _stream_tag
 
         assert env_range is None and len(probabilities) == 1
@@ -154,8 +157,22 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
         fm.initialize_functions([name])
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         _, args, block, grid, _ = self.step_launch()
+        null = np.uint64(0)
+        if batch is not None:
+            import torch
+
+            E, T = int(dm.meta_info("n_envs")), int(self.ticks_per_launch)
+            want = {"obs": ((E, 1, 4), torch.float32), "actions": ((E, 1, 1), torch.int32),
+                    "rewards": ((E, 1), torch.float32), "done": ((E,), torch.int32)}
+            for key, (shape, dtype) in want.items():
+                t = batch[key]
+                assert t.is_cuda and t.is_contiguous() and t.dtype == dtype and t.shape[0] >= T and \
+                    tuple(t.shape[1:]) == shape, (key, tuple(t.shape), t.dtype)
+            batch_args = [batch["obs"], batch["actions"], batch["rewards"], batch["done"]]
+        else:
+            batch_args = [null, null, null, null]
         args = list(args) + [sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0],
-                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)]
+                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)] + batch_args
         return fm.get_function(name), args, block, grid, 0
 
     def step(self, actions=None):

@@ -26,9 +26,12 @@ _ACTIONS = Constants.ACTIONS
 
 
 class RolloutEngine:
-    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True):
+    def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
+                 rollout_batch=None):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
-        [n_envs, n_agents, n_actions_of_head]; None = uniform."""
+        [n_envs, n_agents, n_actions_of_head]; None = uniform.  rollout_batch: the trainer's [T, E, ...] batch
+        tensors for envs whose tick kernel fuses T ticks per launch and records every tick itself
+        (CUDAClassicControlCartPoleEnv.tick_launch)."""
         assert env_wrapper.env_backend == "hip"
         self.w = env_wrapper
         self.sampler = sampler
@@ -64,8 +67,9 @@ class RolloutEngine:
         self.ticks_per_launch = int(getattr(env_wrapper.env, "ticks_per_launch", 1)) if self.fused else 1
         if self.fused:
             # whole tick = ONE launch: sampling, step and reset fused in the env's tick kernel
+            extra = {"batch": rollout_batch} if rollout_batch is not None else {}
             fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
-                                                                        env_wrapper.env_resetter)
+                                                                        env_wrapper.env_resetter, **extra)
             self.plan.add(fn, args, block, grid, shared)
             self.step_entry = 0
             self.step_kernel_name = fn.name
