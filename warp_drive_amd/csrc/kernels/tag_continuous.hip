@@ -16,24 +16,29 @@
 //   tc_fast_impl<KMAX>   N <= 128 agents per replica, K <= KMAX <= 32 observed neighbours
 //     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>).
 //     block = `epb` whole replicas (105 agents -> 1 replica on 128 threads), thread = agent.
-//       fetch    (fused tick) every global input of the trip is issued first: 7 state words per
-//                agent into registers, each wavefront's rows of the two probability tensors
-//                straight into LDS (global_load_lds_dwordx4, 1 KiB per instruction);
+//       fetch    every global LOAD of the tick is issued first (state, step rewards, time step, action
+//                tables; the memory counters return in order, so a load issued later would wait for all
+//                stores issued before it); fused tick: each wavefront's rows of the two probability
+//                tensors go straight into LDS (global_load_lds_dwordx4, 1 KiB per instruction);
 //       sample   (fused tick) Philox4x32-10 + inverse CDF on a running float32 sum, both heads;
 //       move     float32 kinematics exactly as numpy evaluates them (numpy-exact cos/sin);
 //                post-move state staged in LDS (positions; 32-byte feature records);
 //       tags     every runner finds its nearest tagger; tag counts through LDS atomics (their
 //                block barrier is the one after the gather);
-//       search   per agent, in registers, ONE pass over the candidates: the candidate id rides in
+//       search   over the agents still IN THE GAME only (one replica per block: they are packed in
+//                ascending id order -- as candidates, so the chain is as long as the live list, and as
+//                searchers, so a wavefront without a live searcher skips the search; 54 of 105 agents
+//                are in the game on average over an episode of the benchmark policy).  Per searcher,
+//                in registers, ONE pass over the candidates: the candidate's packed index rides in
 //                the low 7 bits of the squared distance through a v_med3_u32 chain that keeps the
 //                K+3 smallest keys; where the first K+1 keys are far enough apart the chain order
 //                is the reference's order and the ids are read off the keys, otherwise the exact
 //                (sqrt(d^2), id) keys of the first K(+1) entries are ranked by pairwise
 //                compare-and-count; ~1e-7 of the agents repeat the search with the two-pass one
 //                (tc_knn_registers: exact K-th distance, compare-mask pass, id-ordered peeling);
-//       ids out  nearest_neighbor_ids leaves through the wavefront's staging buffer (entry k ->
-//                slot k; out-of-order lanes rewrite their rows by rank); 16-bit block-local copies
-//                stay in LDS for the gather; one block barrier;
+//       ids out  packed indices -> agent ids through an LDS table; 16-bit block-local ids per agent
+//                row in LDS (entry k -> slot k; out-of-order lanes rewrite their rows by rank); one
+//                block barrier; nearest_neighbor_ids rows are converted from them and stored;
 //       gather   the block's rows are split evenly over its wavefronts; each WAVEFRONT turns its rows
 //                into observation rows inside a private LDS staging buffer, a chunk of rows at a
 //                time, and streams every chunk out as one contiguous run of write-through 16-byte
