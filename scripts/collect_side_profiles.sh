@@ -38,6 +38,6 @@ run fullobs --full-obs --steps 300 --warmup 30
 run gridworld_E1000 --workload tag_gridworld --steps 2000 --warmup 100
 run gridworld_E100000 --workload tag_gridworld --num-envs 100000 --steps 1000 --warmup 100
 run tc_150agents --num-runners 145 --steps 500 --warmup 50
-run tc_525agents --num-runners 520 --steps 200 --warmup 20
+run tc_505agents --num-runners 500 --steps 500 --warmup 50
 run tc_1005agents --num-runners 1000 --steps 100 --warmup 10
 cat $S

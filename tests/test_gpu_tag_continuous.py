@@ -221,7 +221,7 @@ def test_bench_full_size_properties():
     (False, 6, 8, 30, 6, 23), (True, 6, 8, 30, 6, 23),
     (False, 30, 40, 17, 5, 9),     # probability rows longer than the register path (31 / 41 actions)
     (False, 1, 1, 100, 10, 5),     # two actions per head, the benchmark's agent count
-    (False, 3, 3, 130, 4, 3),      # more than 128 agents: the generic kernel (K-pass selection)
+    (False, 3, 3, 130, 4, 3),      # more than 128 agents: three wavefronts per replica, 9-bit search keys
     (True, 2, 5, 60, 3, 4),        # full observations whose width is a multiple of four (16-byte stores)
     (False, 70, 3, 10, 3, 2),      # action table larger than its LDS copy (71 > 64 entries)
 ])
@@ -449,22 +449,24 @@ def test_exact_and_sqrt_ties_at_the_cut(K):
         assert ids[0, 0, 0] == 1
 
 
-@pytest.mark.parametrize("K", [3, 6])
-def test_candidates_a_few_ulps_apart_at_the_cut(K):
+@pytest.mark.parametrize("K,n_runners", [(3, 10), (6, 10), (3, 180), (6, 180)])
+def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
     """The one-pass search orders candidates by squared distance with the low 7 bits dropped (buckets of
-    128 ulps) and must rebuild the reference's order exactly wherever that is too coarse.  One replica
-    per case: agent 0's K-th and (K+1)-th candidates sit `delta` ulps of squared distance apart --
-    inside one bucket, across a bucket boundary, just inside / outside the 383-apart rule -- with either
-    id the closer one; with `triple` a third candidate shares the zone (the two-pass search takes over).
-    Agents do not move.  Exact comparison with the oracle."""
+    128 ulps; 9 bits = 512 ulps for replicas of more than 128 agents) and must rebuild the reference's
+    order exactly wherever that is too coarse.  One replica per case: agent 0's K-th and (K+1)-th
+    candidates sit `delta` ulps of squared distance apart -- inside one bucket, across a bucket boundary,
+    just inside / outside the 383-apart (1535-apart) rule -- with either id the closer one; with `triple` a
+    third candidate shares the zone (the exact fallback takes over: the two-pass search up to 128
+    candidates, the K-pass scan beyond).  Agents do not move.  Exact comparison with the oracle."""
     from tests.hip_harness import OBS, pull, push_actions
 
-    n_runners = 10
     cfg = dict(num_taggers=2, num_runners=n_runners, grid_length=20.0, episode_length=9, seed=1,
                max_acceleration=0.1, min_acceleration=-0.1, num_acceleration_levels=4, num_turn_levels=4,
                use_full_observation=False, num_other_agents_observed=K, tagging_distance=1e-5,
                runner_exits_game_after_tagged=True)
     deltas = [0, 1, 2, 3, 60, 127, 128, 129, 200, 255, 256, 257, 382, 383, 384, 500, 2000]
+    if n_runners > 126:  # the bucket boundaries of the 9-bit keys
+        deltas += [511, 512, 513, 1023, 1024, 1025, 1534, 1535, 1536, 3000]
     cases = [(d, swap, triple) for d in deltas for swap in (0, 1) for triple in (0, 1)]
     E = len(cases)
     w = _mk(cfg, E)
@@ -490,8 +492,8 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K):
             b3 = f32(np.sqrt(40.0 * np.float64(ulp4)))
             x.append(float(f32(8.0) + b3)); y.append(6.0)
         k = len(x)
-        for j in range(k, N):
-            x.append(14.0 + 0.4 * (j - k)); y.append(15.0)
+        for j in range(k, N):  # the rest far away, on a line inside the arena
+            x.append(14.0 + 5.5 * (j - k) / max(N - k, 1)); y.append(15.0)
         xs[e], ys[e] = np.array(x, f32), np.array(y, f32)
         dx = (xs[e, 0] - xs[e]).astype(f32); dy = (ys[e, 0] - ys[e]).astype(f32)
         d2 = ((dx * dx).astype(f32) + (dy * dy).astype(f32)).astype(f32)
@@ -516,10 +518,13 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K):
             np.testing.assert_array_equal(got[e], want[e], err_msg=f"K={K} t={t} case (delta, swap, triple)={cases[e]}")
 
 
-@pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (525, 5, False), (1020, 3, False)])
+@pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (300, 10, False), (500, 10, False),
+                                                  (525, 5, False), (1020, 3, False)])
 def test_many_agents_paths(n_runners, K, full_obs):
-    """replicas of more than 128 agents: the generic entry points (tc_generic_impl: K-pass selection,
-    one block of up to 1024 threads per replica)"""
+    """replicas of more than 128 agents: up to 512 agents with partial observations take the fast path
+    (blocks of up to eight wavefronts, 9 id bits in the search keys); beyond that, and for full
+    observations, the generic entry points (tc_generic_impl: K-pass selection, one block of up to 1024
+    threads per replica)"""
     cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=30.0, episode_length=6, seed=13,
                max_acceleration=0.2, min_acceleration=-0.2, num_acceleration_levels=5, num_turn_levels=5,
                use_full_observation=full_obs, num_other_agents_observed=K, tagging_distance=0.2,

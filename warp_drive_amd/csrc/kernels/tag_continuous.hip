@@ -671,6 +671,33 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
   tc_rank_entries<KMAX>(sb, rank);
 }
 
+// ---- exact fallback for more than 128 candidates (tc_knn_registers keeps a 128-bit mask): K passes,
+// each picks the smallest (float32 distance, index) key above the previous one.  Slow (K x N square
+// roots) and rare: only a lane with three candidates inside two key buckets at the cut gets here.
+template <int KMAX>
+__device__ __forceinline__ void tc_knn_scan(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX]) {
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
+  float pd = -1.0f;
+  int pj = -1;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    float best = __builtin_inff();
+    int bj = -1;
+    for (int j = 0; j < N; ++j) {
+      const float2 pc = cxy[j];
+      const float dx = xi - pc.x, dy = yi - pc.y;
+      const float d = sqrtf(dx * dx + dy * dy);
+      const bool above = (d > pd) || (d == pd && j > pj);
+      if (j != ag && above && d < best) { best = d; bj = j; }
+    }
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) nid[q] = (q == k) ? bj : nid[q];
+    if (bj < 0) break;  // fewer than K candidates (the remaining entries stay -1)
+    pd = best;
+    pj = bj;
+  }
+}
+
 // ---- neighbour search in ONE pass over the candidates: the candidate's id rides in the low 7 bits
 // of its squared distance (key = d2 bits with the low 7 bits replaced by j; non-negative floats order
 // like unsigned integers) and a v_med3_u32 chain keeps the K+3 smallest keys, so the ids come out of
@@ -699,9 +726,13 @@ __device__ __forceinline__ unsigned tc_umed3(unsigned a, unsigned b, unsigned c)
 
 // nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
 // `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
-template <int KMAX>
+// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512 (buckets of 2^IDB ulps of d2;
+// the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
+// at least 2^(IDB-1) - 1 ulps of the float32 distance)
+template <int KMAX, int IDB>
 __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX + 1],
                                               int (&rank)[KMAX + 1], bool &in_order) {
+  constexpr unsigned IDM = (1u << IDB) - 1u;
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
   unsigned S[L];
@@ -709,7 +740,7 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
   for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
 #define WD_TC_INSERT_KEY(d2v, jv)                                                          \
   do {                                                                                     \
-    const unsigned key_ = (__float_as_uint(d2v) & ~127u) | (unsigned)(jv);                 \
+    const unsigned key_ = (__float_as_uint(d2v) & ~IDM) | (unsigned)(jv);                  \
     _Pragma("unroll") for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_); \
     S[0] = min(S[0], key_);                                                                \
   } while (0)
@@ -766,10 +797,10 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
   unsigned oKth = o[KMAX - 1];  // the K-th other agent in chain order
 #pragma unroll
   for (int k = 0; k < KMAX - 1; ++k) oKth = (k == K - 1) ? o[k] : oKth;
-  const bool apart = (gap >= 383u) && (oKth < 0x7f800000u);  // (and K others are in the game at all)
+  const bool apart = (gap >= 3u * (IDM + 1u) - 1u) && (oKth < 0x7f800000u);  // (and K others are in the game at all)
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    nid[k] = (k < K) ? (int)(o[k] & 127u) : -1;
+    nid[k] = (k < K) ? (int)(o[k] & IDM) : -1;
     rank[k] = k;
   }
   nid[KMAX] = -1;
@@ -786,14 +817,14 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
       oLook = (k == K - 1) ? o[k + 2] : oLook;
     }
     const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
-    const unsigned cut = (oK >> 7) + 2u;   // first bucket that is certainly outside
-    exact = (oK >= INVALID) || ((oLook >> 7) >= cut);
+    const unsigned cut = (oK >> IDB) + 2u;   // first bucket that is certainly outside
+    exact = (oK >= INVALID) || ((oLook >> IDB) >= cut);
     // positions of the first K entries (all reads in flight together), exact keys, ranks
     float2 pp[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       const bool valid = (k < K) && (o[k] < INVALID);
-      nid[k] = valid ? (int)(o[k] & 127u) : -1;
+      nid[k] = valid ? (int)(o[k] & IDM) : -1;
       pp[k] = cxy[valid ? nid[k] : ag];
     }
     unsigned long long key64[KMAX];
@@ -816,8 +847,8 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
     nid[KMAX] = -1;
     rank[KMAX] = KMAX;
     // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
-    if (oK < INVALID && oExtra < INVALID && (oExtra >> 7) < cut) {
-      const int idE = (int)(oExtra & 127u);
+    if (oK < INVALID && oExtra < INVALID && (oExtra >> IDB) < cut) {
+      const int idE = (int)(oExtra & IDM);
       const float2 pe = cxy[idE];
       const float dx = xi - pe.x, dy = yi - pe.y;
       const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
@@ -899,9 +930,12 @@ __device__ __forceinline__ void tc_flush_ids(const unsigned short *src, int *dst
 
 // rows of a wavefront's staging buffer: the host sizes the buffer with the same formula
 // (envs/tag_continuous.py: lds_bytes_fast)
-#define WD_TC_STAGE_TARGET 5400  // bytes of rows per wavefront (19 rows of 71 floats)
-__device__ __forceinline__ int tc_stage_rows(int row_dwords) {
-  return max(1, min(64, WD_TC_STAGE_TARGET / (4 * row_dwords)));
+#define WD_TC_STAGE_TARGET 5400  // bytes of rows per wavefront (19 rows of 71 floats); half of it for blocks of more
+                                 // than four wavefronts (replicas of more than 256 agents), whose LDS also holds
+                                 // the larger replica
+__device__ __forceinline__ int tc_stage_rows(int row_dwords, int n_waves) {
+  const int target = (n_waves > 4) ? WD_TC_STAGE_TARGET / 2 : WD_TC_STAGE_TARGET;
+  return max(1, min(64, target / (4 * row_dwords)));
 }
 
 // LDS of the fast path.  The per-trip area doubles as the two probability slabs of the fused tick,
@@ -914,7 +948,7 @@ struct TcFastLds {
   int *tagcnt;           // [A] tags credited to a tagger this tick
   float2 *xyc;           // one replica per block: [NP] positions of the agents IN THE GAME, packed in ascending id order
                          // (the candidates and the searchers of the neighbour search); else == xy
-  signed char *cid;      // one replica per block: [1 + N] cid[1 + c] = id of the c-th agent in the game, cid[0] = -1
+  short *cid;            // one replica per block: [1 + N] cid[1 + c] = id of the c-th agent in the game, cid[0] = -1
   unsigned short *ids;   // [A][K] block-local neighbour indices (0xffff = none)
   float *stage;          // [n_waves][stage_dwords] wave-private staging buffers
   int stage_dwords;
@@ -936,10 +970,10 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   if (compact) {  // (the host adds the same bytes: envs/tag_continuous.py lds_bytes)
     off = tc_align16(off);
     l.xyc = (float2 *)(p0 + off); off += 8 * (size_t)(((N + 3) & ~3) + 8);
-    l.cid = (signed char *)(p0 + off); off += tc_align16((size_t)N + 1);
+    l.cid = (short *)(p0 + off); off += tc_align16(2 * ((size_t)N + 1));
   }
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
-  l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F) * F) / 4) + 4;
+  l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F, n_waves) * F) / 4) + 4;
   l.stage = (float *)(p0 + off); off += (size_t)4 * l.stage_dwords * n_waves;
   off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
   l.tb = tc_carve_tables(p0 + off, epb, N);
@@ -947,7 +981,7 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
 }
 
 // EXACTK: K == KMAX, known at compile time (row offsets become immediates, the K-dependent selects fold away)
-template <int KMAX, bool FUSED, bool EXACTK>
+template <int KMAX, bool FUSED, bool EXACTK, int IDB>
 __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
                                              int n_turn) {
   const int N = a.N, K = EXACTK ? KMAX : a.K;
@@ -1031,7 +1065,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     if (compact) {
       if (sg) {
         l.xyc[my_c] = make_float2(m.x, m.y);
-        l.cid[1 + my_c] = (signed char)ag;
+        l.cid[1 + my_c] = (short)ag;
       }
       if (ag == 0) l.cid[0] = -1;
     }
@@ -1070,11 +1104,12 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   if (searcher) {
     // one pass with packed keys; a lane with three candidates inside 256 ulps at the cut (~1e-7 per
     // agent) repeats the search with the two-pass one
-    if (!tc_knn_packed<KMAX>(sxy, ag, n_cand, K, nid, rank, in_order)) {
+    if (!tc_knn_packed<KMAX, IDB>(sxy, ag, n_cand, K, nid, rank, in_order)) {
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
-      tc_knn_registers<KMAX>(sxy, ag, n_cand, K, nid2, rank2);
+      if (IDB == 7 || n_cand <= 128) tc_knn_registers<KMAX>(sxy, ag, n_cand, K, nid2, rank2);
+      else tc_knn_scan<KMAX>(sxy, ag, n_cand, K, nid2);  // (entries in the reference's order: rank2[k] = k)
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = rank2[k]; }
       nid[KMAX] = -1;
@@ -1130,7 +1165,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run.
     // A chunk holds at most 192 items (tc_stage_rows), i.e. at most 3 per lane; their (row, slot)
     // split is the same for every chunk and is worked out once.
-    const int R = tc_stage_rows(F);
+    const int R = tc_stage_rows(F, n_waves);
     constexpr int U = 3;
     int rr[U], so[U];
 #pragma unroll
@@ -1507,20 +1542,23 @@ __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
   tc_generic_impl<true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
-// fast entries (N <= 128, partial observations, K <= KM); the host picks the smallest KM >= K
+// fast entries (N <= 512, partial observations, K <= KM); the host picks the smallest KM >= K.  Replicas of
+// more than 128 agents (blocks of up to eight wavefronts) take the copy with 9 id bits in the search keys
 #define WD_TC_SPECIALISE(KM, WAVES)                                                                 \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
-    if (a.K == KM) tc_fast_impl<KM, false, true>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else tc_fast_impl<KM, false, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    if (a.N > 128) tc_fast_impl<KM, false, false, 9>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else if (a.K == KM) tc_fast_impl<KM, false, true, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else tc_fast_impl<KM, false, false, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }                                                                                            \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     WD_TC_FUSE_PACK();                                                                         \
-    if (a.K == KM) tc_fast_impl<KM, true, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else tc_fast_impl<KM, true, false>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    if (a.N > 128) tc_fast_impl<KM, true, false, 9>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else if (a.K == KM) tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else tc_fast_impl<KM, true, false, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }
 WD_TC_SPECIALISE(2, 4)
 WD_TC_SPECIALISE(4, 4)

@@ -285,7 +285,7 @@ class TagContinuous(CUDAEnvironmentContext):
         "num_acceleration_actions", "num_turn_actions",
     ]  # + kEnvBegin appended by step_launch / tick_launch
 
-    FAST_PATH_MAX_AGENTS = 128   # tc_fast_impl: neighbour masks of 4 x 32 bits
+    FAST_PATH_MAX_AGENTS = 512   # tc_fast_impl: blocks of up to 512 threads (9 id bits in the search keys beyond 128 agents)
     STAGE_TARGET_BYTES = 5400    # WD_TC_STAGE_TARGET in tag_continuous.hip
 
     def _fast_path(self):
@@ -315,11 +315,11 @@ class TagContinuous(CUDAEnvironmentContext):
         if self._fast_path():
             F = 7 * K + 1
             n_waves = ((A if threads is None else threads) + 63) // 64
-            stage_rows = max(1, min(64, self.STAGE_TARGET_BYTES // (4 * F)))
+            stage_rows = max(1, min(64, (self.STAGE_TARGET_BYTES // 2 if n_waves > 4 else self.STAGE_TARGET_BYTES) // (4 * F)))
             stage_dwords = align16(4 * stage_rows * F) // 4 + 4
             area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
             if epb == 1:  # packed positions of the agents in the game + the packed-index -> id table
-                area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(N + 1)
+                area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(2 * (N + 1))
             area = align16(area + 2 * A * K) + 4 * stage_dwords * n_waves  # 16-bit neighbour ids, staging
         else:
             area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
