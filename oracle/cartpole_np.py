@@ -68,3 +68,36 @@ class CartPoleOracle:
         self.rewards = np.ones(self.E, f32)
         self.done = np.where((self.timestep == self.T) | terminated, 1, self.done).astype(np.int32)
         return self.obs, self.rewards, self.done
+
+
+def policy_probabilities(packed, hidden, obs, n_actions=2):
+    """float32 restatement of the in-kernel rollout policy (csrc/kernels/cartpole.hip::cp_policy_cum): two hidden
+    layers of `hidden` ReLU units and one softmax head over `packed` = [W0 [H][4], b0, W1 [H][H], b1, Wp [A][H], bp];
+    acc = bias, then one fused multiply-add per input in index order (emulated in float64: the product of two
+    float32 is exact there; the single rounding of the sum to float32 can differ from a hardware fma in the
+    last bit about once in 2^29 operations), softmax with the maximum subtracted.  obs [E, 4] -> probs [E, A]."""
+    f32, H, A = np.float32, int(hidden), int(n_actions)
+    w = np.asarray(packed, dtype=f32)
+    o = 0
+    W0 = w[o:o + 4 * H].reshape(H, 4); o += 4 * H
+    b0 = w[o:o + H]; o += H
+    W1 = w[o:o + H * H].reshape(H, H); o += H * H
+    b1 = w[o:o + H]; o += H
+    Wp = w[o:o + A * H].reshape(A, H); o += A * H
+    bp = w[o:o + A]
+
+    def layer(x, W, b):
+        acc = np.broadcast_to(b, (x.shape[0], W.shape[0])).astype(f32).copy()
+        for j in range(W.shape[1]):
+            acc = (W[None, :, j].astype(np.float64) * x[:, j:j + 1].astype(np.float64) + acc.astype(np.float64)).astype(f32)
+        return acc
+
+    x = np.asarray(obs, dtype=f32)
+    h1 = np.maximum(layer(x, W0, b0), f32(0))
+    h2 = np.maximum(layer(h1, W1, b1), f32(0))
+    logits = layer(h2, Wp, bp)
+    e = np.exp((logits - logits.max(axis=1, keepdims=True)).astype(f32)).astype(f32)
+    s = np.zeros(e.shape[0], f32)
+    for a in range(A):
+        s = (s + e[:, a]).astype(f32)
+    return (e / s[:, None]).astype(f32)

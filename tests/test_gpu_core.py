@@ -486,6 +486,87 @@ def test_cartpole_rollout_records_every_tick():
     assert finished >= 3 * E
 
 
+@pytest.mark.parametrize("hidden", [32, 64])
+def test_cartpole_rollout_with_the_policy_inside_the_kernel(hidden):
+    """HipClassicControlCartPoleEnvRollout_H<hidden>: a whole batch of ticks in one launch, the policy network
+    (two hidden layers, one head; weights in LDS) evaluated by the kernel on every tick's observation.
+    Row k of the recorded batch: the observation must be the oracle's; the action must be the inverse-CDF
+    draw (Philox restated on the host, random.cu:51-85) on the probabilities of oracle/cartpole_np.py::
+    policy_probabilities -- the float32 restatement of the in-kernel forward -- except where the uniform sits
+    within 2e-6 of the decision threshold (device expf vs numpy exp); the oracle then follows the device's
+    action.  And T single-tick launches of the same kernel record the same rows as one T-tick launch."""
+    import torch
+    from oracle.cartpole_np import CartPoleOracle, policy_probabilities
+    from oracle.core_np import fused_tick_uniforms
+    from tests.hip_harness import make_wrapper, pull, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.models import FullyConnected
+    from warp_drive_amd.training.policy_kernel import pack_rollout_policy, rollout_policy_width
+
+    require_gpu()
+    E, T, ticks = 1501, 23, 12
+    torch.manual_seed(5)
+    model = FullyConnected(4, [2], [hidden, hidden])
+    with torch.no_grad():  # (make the policy decisive enough that both actions occur with varied probabilities)
+        model.policy_head[0].weight.mul_(6.0)
+    assert rollout_policy_width(model, 4) == hidden
+    packed = pack_rollout_policy(model).cuda()
+
+    def make(tpl):
+        env = CUDAClassicControlCartPoleEnv(episode_length=T, seed=32145)
+        env.ticks_per_launch = tpl
+        w = make_wrapper(env, E)
+        sampler = HIPSampler(w.cuda_function_manager)
+        sampler.init_random(seed=4)
+        probs = torch.full((E, 1, 2), 0.5, device="cuda")
+        rows = max(tpl, 1)
+        batch = {"obs": torch.full((rows, E, 1, 4), 7.0, device="cuda"),
+                 "actions": torch.full((rows, E, 1, 1), -1, dtype=torch.int32, device="cuda"),
+                 "rewards": torch.full((rows, E, 1), -1.0, device="cuda"),
+                 "done": torch.full((rows, E), -1, dtype=torch.int32, device="cuda")}
+        eng = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch, rollout_policy=(packed, hidden))
+        assert eng.step_kernel_name == f"HipClassicControlCartPoleEnvRollout_H{hidden}"
+        return w, sampler, batch, eng
+
+    w, sampler, batch, eng = make(ticks)
+    w1, _, batch1, eng1 = make(1)
+    orc = CartPoleOracle(E, T, initial_state=pull(w, "state")[0, 0])
+    rng_words = np.zeros(4 + E, dtype=np.uint32)
+    near = draws = finished = 0
+    for launch in range(5):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        eng.run(1)
+        torch.cuda.synchronize()
+        b = {k: v.cpu().numpy() for k, v in batch.items()}
+        for k in range(ticks):
+            eng1.run(1)  # the same tick as its own launch
+            torch.cuda.synchronize()
+            for key in b:
+                np.testing.assert_array_equal(batch1[key][0].cpu().numpy(), b[key][k], err_msg=f"{key} row {k}")
+            np.testing.assert_array_equal(b["obs"][k, :, 0], orc.obs, err_msg=f"obs row {k} of launch {launch}")
+            p = policy_probabilities(packed.cpu().numpy(), hidden, orc.obs)
+            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            want = (p[:, 0] < u).astype(np.int32)  # number of running sums below u, clamped to the last action
+            got = b["actions"][k, :, 0, 0]
+            bad = got != want
+            assert (np.abs(p[bad, 0] - u[bad]) < 2e-6).all(), (launch, k, p[bad, 0], u[bad])
+            near += int(bad.sum())
+            draws += E
+            orc.step(got.reshape(E, 1, 1))
+            np.testing.assert_array_equal(b["rewards"][k, :, 0], orc.rewards)
+            np.testing.assert_array_equal(b["done"][k], orc.done)
+            finished += int((orc.done > 0).sum())
+            orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "state")[:, 0], orc.state)
+        np.testing.assert_array_equal(pull(w1, "state")[:, 0], orc.state)
+    frac1 = float((b["actions"] == 1).mean())
+    assert finished >= 2 * E and near <= 2 + draws // 100000 and 0.1 < frac1 < 0.9, (finished, near, frac1)
+
+
 def test_consistency_checker_api():
     """The reference's own parity harness, at 1e-5 instead of 1 % (its scenarios:
     tests/example_envs/pycuda_tests/test_tag_continuous.py:15-80, test_tag_gridworld.py:13-38)."""

@@ -99,6 +99,25 @@ def test_update_in_bf16_and_downsampling_keys(tmp_path):
         assert abs(a - b) <= 5e-2 * max(abs(a), 1e-3), (pol, a, b)
 
 
+def test_cartpole_trains_with_the_whole_batch_rollout_in_one_launch(tmp_path):
+    """single_cartpole's [32, 32] policy is evaluated inside the env's rollout kernel: one launch per training
+    batch.  It must train (finite loss, changing weights), keep the episodic-reward bookkeeping of the per-tick
+    path (Cartpole pays 1 per tick: the mean episodic reward is the mean episode length, between 8 and the
+    episode length), and the per-tick path stays available (`fused_rollout_policy: False`)."""
+    ov = {"trainer": {"num_envs": 200, "train_batch_size": 200 * 40, "num_episodes": 400},
+          "env": {"episode_length": 60}, "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
+    trainer, metrics = _train("single_cartpole", ov, tmp_path / "one_launch", iters=3)
+    assert trainer._batch_rollout is not None
+    assert trainer.engine.step_kernel_name == "HipClassicControlCartPoleEnvRollout_H32"
+    assert 8.0 <= metrics["shared"]["Mean episodic reward"] <= 60.0, metrics["shared"]["Mean episodic reward"]
+    ov["trainer"]["fused_rollout_policy"] = False
+    trainer2, metrics2 = _train("single_cartpole", ov, tmp_path / "per_tick", iters=3)
+    assert trainer2._batch_rollout is None
+    assert 8.0 <= metrics2["shared"]["Mean episodic reward"] <= 60.0
+    # same env, same random policy at the start: the two rollouts see episodes of the same length on average
+    assert abs(metrics["shared"]["Mean episodic reward"] - metrics2["shared"]["Mean episodic reward"]) < 8.0
+
+
 def test_graph_and_eager_rollouts_agree(tmp_path):
     """the hipGraph replay of a rollout tick must produce exactly what the eager tick produces"""
     from tests.hip_harness import require_gpu

@@ -41,36 +41,75 @@ __device__ __forceinline__ bool cp_euler(float4 &s, int action, const CpPhysics 
          theta > p.theta_threshold_radians;
 }
 
+// ---- a small policy INSIDE the rollout kernel: two hidden layers of H units + one softmax head, the
+// weights in LDS (every lane reads the same address: broadcast), the activations in registers.
+// Packed weights (training/policy_kernel.py::pack_rollout_policy): W0 [H][4], b0 [H], W1 [H][H], b1 [H],
+// Wp [A][H], bp [A], all float32.  Arithmetic: acc = bias, then fmaf over the inputs in index order;
+// softmax with the maximum subtracted, expf, one division per action; restated in
+// oracle/cartpole_np.py::policy_probabilities.  Returns the running float32 sums of the probabilities
+// (what the inverse-CDF sampler compares the uniform with, random.cu:51-85).
+constexpr int CP_MAX_REG_ACTIONS = 8;
+
+template <int H>
+__device__ __forceinline__ void cp_policy_cum(const float *w, const float4 &s, int n_actions,
+                                              float (&cumv)[CP_MAX_REG_ACTIONS]) {
+  const float *W0 = w, *b0 = W0 + 4 * H, *W1 = b0 + H, *b1 = W1 + H * H, *Wp = b1 + H, *bp = Wp + n_actions * H;
+  float h1[H], h2[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float4 wr = *(const float4 *)(W0 + 4 * i);
+    float acc = b0[i];
+    acc = fmaf(wr.x, s.x, acc); acc = fmaf(wr.y, s.y, acc); acc = fmaf(wr.z, s.z, acc); acc = fmaf(wr.w, s.w, acc);
+    h1[i] = fmaxf(acc, 0.0f);
+  }
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    float acc = b1[i];
+#pragma unroll
+    for (int j = 0; j < H; j += 4) {
+      const float4 wr = *(const float4 *)(W1 + i * H + j);
+      acc = fmaf(wr.x, h1[j], acc); acc = fmaf(wr.y, h1[j + 1], acc);
+      acc = fmaf(wr.z, h1[j + 2], acc); acc = fmaf(wr.w, h1[j + 3], acc);
+    }
+    h2[i] = fmaxf(acc, 0.0f);
+  }
+  float logit[CP_MAX_REG_ACTIONS], m = -__builtin_inff();
+#pragma unroll
+  for (int a = 0; a < CP_MAX_REG_ACTIONS; ++a) {
+    logit[a] = -__builtin_inff();
+    if (a < n_actions) {
+      float acc = bp[a];
+#pragma unroll
+      for (int j = 0; j < H; j += 4) {
+        const float4 wr = *(const float4 *)(Wp + a * H + j);
+        acc = fmaf(wr.x, h2[j], acc); acc = fmaf(wr.y, h2[j + 1], acc);
+        acc = fmaf(wr.z, h2[j + 2], acc); acc = fmaf(wr.w, h2[j + 3], acc);
+      }
+      logit[a] = acc;
+      m = fmaxf(m, acc);
+    }
+  }
+  float e[CP_MAX_REG_ACTIONS], sum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < CP_MAX_REG_ACTIONS; ++a) {
+    e[a] = (a < n_actions) ? expf(logit[a] - m) : 0.0f;
+    sum += e[a];
+  }
+  float cum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < CP_MAX_REG_ACTIONS; ++a) {
+    const float p = e[a] / sum;
+    if (a < n_actions) cum = (a == 0) ? p : cum + p;
+    cumv[a] = cum;
+  }
+}
+
 struct CpResetEntry {  // same layout as wd_reset_entry in wd_core.hip
   uint32_t *data;
   const uint32_t *ref;
   int row_elems;
   int pad_;
 };
-
-}  // namespace
-
-extern "C" {
-
-__global__ void HipClassicControlCartPoleEnvStep(
-    float4 *__restrict__ state_arr, const int *__restrict__ action_arr, int *__restrict__ done_arr,
-    float *__restrict__ reward_arr, float4 *__restrict__ observation_arr, float gravity,
-    float masspole, float total_mass, float length, float polemass_length, float force_mag,
-    float tau, float theta_threshold_radians, float x_threshold,
-    int *__restrict__ env_timestep_arr, int episode_length, int n_envs) {
-  const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
-                    theta_threshold_radians, x_threshold};
-  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
-    const int t = env_timestep_arr[env] + 1;
-    env_timestep_arr[env] = t;
-    float4 s = state_arr[env];
-    const bool terminated = cp_euler(s, action_arr[env], p);
-    state_arr[env] = s;
-    observation_arr[env] = s;
-    reward_arr[env] = 1.0f;
-    if (t == episode_length || terminated) done_arr[env] = 1;
-  }
-}
 
 // Fused rollout tick(s): sample the action + step + reset a finished replica, `ticks` times per launch
 // with the state kept in registers (a single tick at E = 100 000 moves 6.8 MB: under 1 us of HBM time,
@@ -82,19 +121,31 @@ __global__ void HipClassicControlCartPoleEnvStep(
 // the observation the policy acted on, the sampled action, the reward and the done flag, exactly what
 // trainer_base.py:392-426 records per tick -- so T ticks move T times the bytes (28 B per env-step,
 // all coalesced: the real HBM ceiling run of configs[4]); the per-tick arrays then receive the last
-// tick only.  (No __restrict__ on the arrays: the reset table aliases them.)
-__global__ void HipClassicControlCartPoleEnvTick(
+// tick only.  With `policy` (packed weights of a two-hidden-layer MLP of width `hidden` = 32 or 64 and one
+// head, in dynamic LDS) the rollout runs with a LIVE policy: every tick evaluates the network on the
+// replica's current observation instead of reading `probs` -- a whole training batch of ticks is then
+// one launch (the reference runs policy forward, sampler, step and reset as separate launches with
+// three host synchronisations per tick, trainer_base.py:392-426).
+// (No __restrict__ on the arrays: the reset table aliases them.)
+template <int H>
+__device__ __forceinline__ void cp_tick_impl(float *cp_weights,
     float4 *state_arr, int *action_arr, int *done_arr,
     float *reward_arr, float4 *observation_arr, float gravity,
     float masspole, float total_mass, float length, float polemass_length, float force_mag,
     float tau, float theta_threshold_radians, float x_threshold,
     int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
-    int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch) {
+    int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
+    const float *policy, int hidden) {
   const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
                     theta_threshold_radians, x_threshold};
   const CpResetEntry *table = (const CpResetEntry *)reset_table;
   const uint32_t k0 = rng_state[0], k1 = rng_state[1];
+  if (H > 0) {
+    const int n_w = 4 * H + H + H * H + H + n_actions * H + n_actions;
+    for (int i = threadIdx.x; i < n_w; i += blockDim.x) cp_weights[i] = policy[i];
+    __syncthreads();
+  }
   for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
     int t = env_timestep_arr[env];
     float4 s = state_arr[env];
@@ -103,9 +154,8 @@ __global__ void HipClassicControlCartPoleEnvTick(
     // The running float32 sums of the (fixed) probabilities, once per launch and in registers: a load
     // inside the tick loop would wait for every store issued before it (the memory counters return in
     // order) -- 2.9 us per tick at 100 000 replicas instead of 0.5.
-    constexpr int CP_MAX_REG_ACTIONS = 8;
     float cumv[CP_MAX_REG_ACTIONS];
-    {
+    if (H == 0) {
       float cum = 0.0f;
 #pragma unroll
       for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) {
@@ -117,6 +167,7 @@ __global__ void HipClassicControlCartPoleEnvTick(
       // ---- sample (random.cu:51-85): inverse CDF on a running float32 sum
       const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, 3u}, k0, k1);
       const float u = wd_u01_open_closed(rnd.x);
+      if (H > 0) cp_policy_cum<(H > 0 ? H : 4)>(cp_weights, s, n_actions, cumv);  // live policy: THIS tick's observation
       int cnt = 0;
       if (n_actions <= CP_MAX_REG_ACTIONS) {
 #pragma unroll
@@ -165,5 +216,58 @@ __global__ void HipClassicControlCartPoleEnvTick(
     rng_state[WD_RNG_HEADER + env] = epoch0 + (uint32_t)ticks;
   }
 }
+
+}  // namespace
+
+extern "C" {
+
+__global__ void HipClassicControlCartPoleEnvStep(
+    float4 *__restrict__ state_arr, const int *__restrict__ action_arr, int *__restrict__ done_arr,
+    float *__restrict__ reward_arr, float4 *__restrict__ observation_arr, float gravity,
+    float masspole, float total_mass, float length, float polemass_length, float force_mag,
+    float tau, float theta_threshold_radians, float x_threshold,
+    int *__restrict__ env_timestep_arr, int episode_length, int n_envs) {
+  const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
+                    theta_threshold_radians, x_threshold};
+  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
+    const int t = env_timestep_arr[env] + 1;
+    env_timestep_arr[env] = t;
+    float4 s = state_arr[env];
+    const bool terminated = cp_euler(s, action_arr[env], p);
+    state_arr[env] = s;
+    observation_arr[env] = s;
+    reward_arr[env] = 1.0f;
+    if (t == episode_length || terminated) done_arr[env] = 1;
+  }
+}
+
+__global__ void HipClassicControlCartPoleEnvTick(
+    float4 *state_arr, int *action_arr, int *done_arr,
+    float *reward_arr, float4 *observation_arr, float gravity,
+    float masspole, float total_mass, float length, float polemass_length, float force_mag,
+    float tau, float theta_threshold_radians, float x_threshold,
+    int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
+    const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
+    int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
+    const float *policy, int hidden) {
+  cp_tick_impl<0>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+}
+
+// the rollout with a live policy (weights in dynamic LDS); `hidden` must equal the entry's width
+#define WD_CP_ROLLOUT(HH)                                                                          \
+  __global__ void __launch_bounds__(256, 2) HipClassicControlCartPoleEnvRollout_H##HH(             \
+    float4 *state_arr, int *action_arr, int *done_arr, \
+    float *reward_arr, float4 *observation_arr, float gravity, \
+    float masspole, float total_mass, float length, float polemass_length, float force_mag, \
+    float tau, float theta_threshold_radians, float x_threshold, \
+    int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state, \
+    const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays, \
+    int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch, \
+    const float *policy, int hidden) {           \
+    extern __shared__ __attribute__((aligned(16))) float cp_lds[];                                 \
+    cp_tick_impl<HH>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);                                                \
+  }
+WD_CP_ROLLOUT(32)
+WD_CP_ROLLOUT(64)
 
 }  // extern "C"

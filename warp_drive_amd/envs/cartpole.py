@@ -142,18 +142,32 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
     TICK_HEADS = 1          # action heads the fused tick kernel samples (RolloutEngine)
     ticks_per_launch = 1    # > 1: fixed-policy rollout, T ticks fused per launch (the HBM-ceiling run)
 
-    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None):
+    ROLLOUT_POLICY_WIDTHS = (32, 64)   # HipClassicControlCartPoleEnvRollout_H<width>
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None, policy=None):
         """Fused rollout tick(s): sample + step + reset of a finished replica, `ticks_per_launch`
         times in ONE launch (HipClassicControlCartPoleEnvTick).  probabilities = [float32 CUDA tensor
         [E, 1, n_actions]]; `_done_` reports the last tick of the launch.  `batch` (optional) = the
         trainer's batch tensors {"obs": [T, E, 1, 4] float32, "actions": [T, E, 1, 1] int32, "rewards":
         [T, E, 1] float32, "done": [T, E] int32} with T >= ticks_per_launch: tick k of the launch writes
-        their row k (what trainer_base.py:392-426 records per tick)."""
+        their row k (what trainer_base.py:392-426 records per tick).  `policy` (optional) = (packed float32
+        CUDA tensor from training.policy_kernel.pack_rollout_policy, hidden width): the launch evaluates the
+        policy network on every tick's observation itself (HipClassicControlCartPoleEnvRollout_H<width>)
+        instead of reading `probabilities`."""
         from warp_drive_amd.managers.function_manager import _stream_tag
 
         assert env_range is None and len(probabilities) == 1
         fm, dm = self.cuda_function_manager, self.cuda_data_manager
         name = self.cuda_step.name.replace("Step", "Tick")
+        shared, pol_args = 0, [np.uint64(0), np.int32(0)]
+        if policy is not None:
+            packed, width = policy
+            n_act = int(probabilities[0].shape[-1])
+            assert width in self.ROLLOUT_POLICY_WIDTHS and n_act <= 8
+            n_w = 4 * width + width + width * width + width + n_act * width + n_act
+            assert packed.is_cuda and packed.dtype.is_floating_point and packed.numel() == n_w and packed.is_contiguous()
+            name = self.cuda_step.name.replace("Step", f"Rollout_H{width}")
+            shared, pol_args = 4 * n_w, [packed, np.int32(width)]
         fm.initialize_functions([name])
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         _, args, block, grid, _ = self.step_launch()
@@ -172,8 +186,8 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
         else:
             batch_args = [null, null, null, null]
         args = list(args) + [sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0],
-                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)] + batch_args
-        return fm.get_function(name), args, block, grid, 0
+                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)] + batch_args + pol_args
+        return fm.get_function(name), args, block, grid, shared
 
     def step(self, actions=None):
         self.timestep += 1

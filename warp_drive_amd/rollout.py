@@ -27,11 +27,12 @@ _ACTIONS = Constants.ACTIONS
 
 class RolloutEngine:
     def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
-                 rollout_batch=None):
+                 rollout_batch=None, rollout_policy=None):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform.  rollout_batch: the trainer's [T, E, ...] batch
         tensors for envs whose tick kernel fuses T ticks per launch and records every tick itself
-        (CUDAClassicControlCartPoleEnv.tick_launch)."""
+        (CUDAClassicControlCartPoleEnv.tick_launch); rollout_policy: (packed weights, hidden width) of a small policy
+        that such a kernel evaluates itself on every tick."""
         assert env_wrapper.env_backend == "hip"
         self.w = env_wrapper
         self.sampler = sampler
@@ -68,6 +69,8 @@ class RolloutEngine:
         if self.fused:
             # whole tick = ONE launch: sampling, step and reset fused in the env's tick kernel
             extra = {"batch": rollout_batch} if rollout_batch is not None else {}
+            if rollout_policy is not None:
+                extra["policy"] = rollout_policy
             fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
                                                                         env_wrapper.env_resetter, **extra)
             self.plan.add(fn, args, block, grid, shared)

@@ -124,3 +124,29 @@ class FusedPolicyForward:
         block_rows = self.WAVES_PER_BLOCK * _WAVE_ROWS
         grid = ((n_rows + block_rows - 1) // block_rows, 1)
         self.fn(*args, block=(64 * self.WAVES_PER_BLOCK, 1, 1), grid=grid, shared=self.lds_bytes)
+
+
+def rollout_policy_width(model, obs_size, widths=(32, 64)):
+    """hidden width if `model` (training.models.FullyConnected) is a network the in-kernel rollout policies
+    evaluate -- two hidden layers of equal width in `widths`, one action head -- else None"""
+    fc = [model.fc[str(i)][0] for i in range(len(model.fc))]
+    if len(fc) != 2 or len(model.policy_head) != 1 or fc[0].in_features != int(obs_size):
+        return None
+    w = fc[0].out_features
+    if w not in widths or fc[1].in_features != w or fc[1].out_features != w or model.policy_head[0].in_features != w:
+        return None
+    return int(w)
+
+
+@torch.no_grad()
+def pack_rollout_policy(model, out=None):
+    """W0 [H][obs], b0 [H], W1 [H][H], b1 [H], Wp [A][H], bp [A] as one flat float32 tensor (the layout
+    csrc/kernels/cartpole.hip::cp_policy_cum reads from LDS).  `out`: refill an existing tensor in place (the
+    launch plan holds its address)."""
+    parts = [model.fc["0"][0].weight, model.fc["0"][0].bias, model.fc["1"][0].weight, model.fc["1"][0].bias,
+             model.policy_head[0].weight, model.policy_head[0].bias]
+    flat = torch.cat([p.detach().float().reshape(-1) for p in parts])
+    if out is None:
+        return flat.contiguous()
+    out.copy_(flat)
+    return out

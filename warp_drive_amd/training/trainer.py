@@ -31,7 +31,7 @@ from warp_drive_amd.training.data_loader import create_and_push_data_placeholder
 from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
-from warp_drive_amd.training.policy_kernel import FusedPolicyForward
+from warp_drive_amd.training.policy_kernel import FusedPolicyForward, pack_rollout_policy, rollout_policy_width
 from warp_drive_amd.utils.constants import Constants
 
 _ACTIONS, _REWARDS, _OBSERVATIONS = Constants.ACTIONS, Constants.REWARDS, Constants.OBSERVATIONS
@@ -203,6 +203,26 @@ class Trainer:
                 if FusedPolicyForward.supports(m, obs_size) and self.obs.dtype == torch.float32:
                     self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size)
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
+        # ---- whole-batch rollout in ONE launch: envs whose tick kernel can evaluate a small policy itself
+        # (Cartpole: two hidden layers of 32 / 64 units, one head; csrc/kernels/cartpole.hip) run all
+        # `batch_len` ticks of a training batch -- policy forward, sampling, step, reset, recording of the
+        # batch rows -- in a single launch.  `trainer.fused_rollout_policy: False` keeps the per-tick path.
+        self._batch_rollout = None
+        env = env_wrapper.env
+        if (bool(tcfg.get("fused_rollout_policy", True)) and self.engine.fused and len(self.policies) == 1
+                and hasattr(env, "ROLLOUT_POLICY_WIDTHS") and self._rollout_dtype is None and self.batch_len > 1):
+            pol = self.policies[0]
+            obs_size = flattened_obs_size(env.observation_space[self.policy_map[pol][0]])
+            width = rollout_policy_width(self.models[pol], obs_size, env.ROLLOUT_POLICY_WIDTHS)
+            if width is not None and len(self.head_sizes) == 1 and self.head_sizes[0] <= 8:
+                env.ticks_per_launch = self.batch_len
+                packed = pack_rollout_policy(self.models[pol]).to(self.device)
+                batch = {"obs": self.batch[pol]["obs"], "actions": self.batch[pol]["actions"],
+                         "rewards": self.batch[pol]["rewards"], "done": self.done_batch}
+                self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
+                                            rollout_batch=batch, rollout_policy=(packed, width))
+                self._batch_rollout = {"policy": pol, "packed": packed}
+                self._want_graph = False
 
     # --------------------------------------------------------------------------- rollout
     def _inference_model(self, pol):
@@ -274,7 +294,33 @@ class Trainer:
             torch.cuda.synchronize()
             return None
 
+    @torch.no_grad()
+    def _generate_rollout_batch_in_one_launch(self):
+        """the whole batch of ticks as ONE launch (the kernel evaluates the policy itself), then the episodic
+        reward bookkeeping of `_tick`, vectorised over the recorded rows"""
+        br = self._batch_rollout
+        pol = br["policy"]
+        pack_rollout_policy(self.models[pol], out=br["packed"])  # the weights of this iteration
+        self.engine.run(1)
+        T = self.batch_len
+        r = self.batch[pol]["rewards"][:T]                       # [T, E, n]
+        d = self.done_batch[:T] > 0                              # [T, E]
+        total = torch.cumsum(r, dim=0) + self._ep_reward[pol][None]  # reward since the last start carried in
+        idx = torch.arange(T, device=self.device)[:, None].expand(T, self.num_envs)
+        last = torch.where(d, idx, torch.full_like(idx, -1)).cummax(dim=0).values   # latest finished tick <= t
+        prev = torch.cat([torch.full_like(last[:1], -1), last[:-1]], dim=0)         # ... < t
+        base = torch.gather(total, 0, prev.clamp(min=0)[..., None].expand_as(total))
+        base = torch.where((prev >= 0)[..., None], base, torch.zeros_like(base))
+        episode = total - base                                   # reward of the running episode up to tick t
+        self._ep_sum[pol] += (episode.mean(dim=2) * d).sum()
+        self._ep_cnt += d.sum()
+        end = last[-1]                                           # [E]
+        carried = torch.gather(total, 0, end.clamp(min=0)[None, :, None].expand(1, *total.shape[1:]))[0]
+        self._ep_reward[pol] = torch.where((end >= 0)[:, None], total[-1] - carried, total[-1])
+
     def _generate_rollout_batch(self):
+        if self._batch_rollout is not None:
+            return self._generate_rollout_batch_in_one_launch()
         if self._tick_graph is None and self._want_graph:
             self._tick_graph = self._capture_tick_graph()
             self._want_graph = self._tick_graph is not None
