@@ -5,7 +5,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from warp_drive_amd.training.scripts.train import setup_trainer
 for one_launch, batch in ((False, 1000000), (True, 1000000), (True, 5000000)):
-    ov = {"trainer": {"fused_rollout_policy": one_launch, "train_batch_size": batch}}
+    ov = {"trainer": {"fused_rollout_policy": one_launch, "train_batch_size": batch, "num_episodes": 10000000}}
     tr = setup_trainer("single_cartpole", ov, results_dir=f"/tmp/cp_{int(one_launch)}_{batch}", verbose=False)
     tr._generate_rollout_batch(); torch.cuda.synchronize()
     t0 = time.perf_counter()
