@@ -13,7 +13,7 @@
 //
 // Two implementations share the move / reward code:
 //
-//   tc_fast_impl<KMAX>   N <= 128 agents per replica, K <= KMAX <= 32 observed neighbours
+//   tc_fast_impl<KMAX>   N <= 512 agents per replica, K <= KMAX <= 32 observed neighbours
 //     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>).
 //     block = `epb` whole replicas (105 agents -> 1 replica on 128 threads), thread = agent.
 //       fetch    every global LOAD of the tick is issued first (state, step rewards, time step, action
@@ -412,7 +412,7 @@ __device__ __forceinline__ void tc_reset_finished(const TcArgs &a, const TcFuse 
 }
 
 // =====================================================================================
-//                   fast path: N <= 128, partial observations, K <= KMAX
+//                   fast path: N <= 512, partial observations, K <= KMAX
 // =====================================================================================
 
 struct TcP4 {

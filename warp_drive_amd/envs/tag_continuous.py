@@ -293,7 +293,7 @@ class TagContinuous(CUDAEnvironmentContext):
                 and 1 <= self.num_other_agents_observed <= _K_SPECIALISATIONS[-1])
 
     def resolve_step_function_name(self, default_name):
-        """The register-resident top-K specialisation that covers K (N <= 128, partial obs), else the
+        """The register-resident top-K specialisation that covers K (N <= 512, partial obs), else the
         generic kernel."""
         if not self._fast_path():
             return default_name
