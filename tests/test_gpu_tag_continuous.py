@@ -390,6 +390,62 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     assert near_tie <= max(2, rows // 100000), (near_tie, rows)
 
 
+def test_whole_episode_at_the_headline_shape():
+    """The neighbour search runs over the agents still in the game, packed: 105 of them at the start of an
+    episode, fewer than 64 (one wavefront of searchers, the second one skips the search) from about tick 150
+    on, ~27 at tick 500 under a uniform random policy -- and 105 again after the restart.  The fused tick at
+    the BASELINE shape runs a whole 500-tick episode plus the first 60 ticks of the next one with 48
+    replicas; every tick is compared with the C oracle (actions replayed, state / observations / rewards /
+    done / nearest ids exact) and the live-agent count must really sweep the range."""
+    import torch
+    from oracle.tag_continuous_c import TagContinuousCOracle
+    from tests.hip_harness import OBS, REW, pull, require_gpu
+    from warp_drive_amd.env_wrapper import EnvWrapper
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.managers.function_manager import HIPSampler
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    require_gpu()
+    E, cfg = 48, dict(BENCH_CFG)
+    w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
+    w.reset_all_envs()
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=99)
+    create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                      push_data_batch_placeholders=False)
+    engine = RolloutEngine(w, sampler)  # uniform probabilities: the benchmark's policy
+    assert engine.step_kernel_name == "HipTagContinuousTick_K10"
+    orc = TagContinuousCOracle(E, n_threads=min(16, os.cpu_count() or 1), **cfg)
+    live_seen, near_tie, rows = [], 0, 0
+    for t in range(560):
+        engine.run(1)
+        torch.cuda.synchronize()
+        orc.step(pull(w, "sampled_actions"))
+        np.testing.assert_array_equal(pull(w, REW), orc.rewards, err_msg=f"rewards t={t}")
+        np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")
+        fin = orc.done > 0
+        obs_before_reset = orc.obs[~fin].copy()
+        orc.reset_done_envs()
+        for name, attr in STATE:
+            np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
+        obs_dev = pull(w, OBS)
+        np.testing.assert_array_equal(obs_dev[fin], orc.obs[fin])
+        live = np.flatnonzero(~fin)
+        if not np.array_equal(obs_dev[live], obs_before_reset):
+            bad = np.argwhere((obs_dev[live] != obs_before_reset).any(axis=2))
+            bad[:, 0] = live[bad[:, 0]]
+            assert _near_tie_rows_c(orc, bad), f"obs mismatch that is not a near-tie t={t}: {bad[:5]}"
+            near_tie += len(bad)
+        rows += E * 105
+        live_seen.append(float(orc.sig.sum(axis=1).mean()))
+    _TOTALS["near_tie_rows"] += near_tie
+    _TOTALS["rows"] += rows
+    assert near_tie <= 2, near_tie
+    # the episode did sweep the packed-search regimes: two wavefronts of searchers, then one, then 105 again
+    assert max(live_seen[:20]) > 95 and min(live_seen[400:499]) < 45 and live_seen[505] > 95, (live_seen[:3], live_seen[480:510:5])
+
+
 def _push_state(w, **arrays):
     """overwrite device state arrays in place (any registered array, torch-accessible or not)"""
     import torch
