@@ -50,7 +50,8 @@ PROFILE = [
     (TC, "  in_order = apart;\n  if (!apart) {", "  in_order = apart;\n  if (!apart) {\n    if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();"),
     (TC, "  // ------------------------------------------------------------ ids out: block-local 16-bit neighbour",
      "  TC_STAMP(9);\n  // ---- ids out: block-local 16-bit neighbour"),
-    (TC, "  {\n    // observation rows, R rows per chunk:", "  TC_STAMP(10);\n  {\n    // observation rows, R rows per chunk:"),
+    (TC, "  // the sparse form pays when few rows are live (late in an episode); wave-uniform choice",
+     "  TC_STAMP(10);\n  // the sparse form pays when few rows are live (late in an episode); wave-uniform choice"),
     (TC, "  __syncthreads();  // every runner's tag is counted\n", "  TC_STAMP(11);\n  __syncthreads();\n  TC_STAMP(12);\n"),
     (TC, "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n}\n", "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n  TC_STAMP(13); TC_STAMP_RT(15);\n}\n"),
 ]

@@ -78,6 +78,9 @@ struct TcArgs {
   int *done, *timestep;
   int N, T, E;
   int env_begin;  // first replica of this launch (a launch covers replicas [env_begin, E))
+  int *obs_rows_cleared;  // [E, N] 1 = the agent's observation row in HBM is all zeros already: rows of agents out
+                          // of the game are zeros until the episode restarts (:476-560), so the sparse form of the
+                          // row gather clears such a row ONCE instead of rewriting it every tick
 };
 
 // extra inputs of the fused rollout tick (sample both action heads -> step -> reset finished
@@ -153,12 +156,13 @@ struct TcIn {
   float step_reward;   // step_rewards[agent]
   int tstep, nrun;     // lane of agent 0: _timestep_ / num_runners of the replica
   float tab_acc, tab_turn;  // entry `tid` of the two action tables (tables of at most WD_TC_TAB entries)
+  int cleared;              // obs_rows_cleared[agent] (fast path)
 };
 
 template <bool FUSED>
 __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const TcFuse &fz, int env0, int epb,
                                                int N, int n_acc, int n_turn, int tid, float *slab_acc,
-                                               float *slab_turn) {
+                                               float *slab_turn, bool want_cleared = false) {
   const int el = tid / N, ag = tid - el * N;
   const int env = env0 + el;
   const bool active = (el < epb) && (env < a.E);
@@ -169,6 +173,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
   in.step_reward = 0.f;
   in.tstep = in.nrun = 0;
   in.tab_acc = in.tab_turn = 0.f;
+  in.cleared = 0;
   if (n_acc <= WD_TC_TAB && n_turn <= WD_TC_TAB) {  // (a block has at least 64 threads)
     if (tid < n_acc) in.tab_acc = a.acc_actions[tid];
     if (tid < n_turn) in.tab_turn = a.turn_actions[tid];
@@ -184,6 +189,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
     in.type = a.agent_types[ag];
     // (the counters return in order: a load issued after the tick's stores would wait for all of them)
     in.step_reward = a.step_rewards[ag];
+    if (want_cleared) in.cleared = a.obs_rows_cleared[gi];
     if (ag == 0) {
       in.tstep = a.timestep[env];
       in.nrun = a.num_runners[env];
@@ -973,12 +979,187 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
     l.cid = (short *)(p0 + off); off += tc_align16(2 * ((size_t)N + 1));
   }
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
-  l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F, n_waves) * F) / 4) + 4;
+  l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F, n_waves) * F) / 4) + 4 + 16;  // + the list of live rows (64 bytes)
   l.stage = (float *)(p0 + off); off += (size_t)4 * l.stage_dwords * n_waves;
   off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
   l.tb = tc_carve_tables(p0 + off, epb, N);
   return l;
 }
+
+// ---- observation rows of one wavefront, SPARSE form (chosen per wavefront when at most 9/16 of its rows
+// belong to agents in the game: late in an episode; the dense form -- contiguous chunks of rows, every row
+// computed and written -- is cheaper per row but moves every byte): rows [wrow0, wrow0 + wrows) of the block.
+// A row of an agent that is out of the game is all zeros until the episode restarts (:476-560): it is
+// cleared ONCE, on the first tick the agent is out (bit 1 of l.sig / obs_rows_cleared remember it), and
+// costs nothing afterwards -- under the benchmark's own policy half of the rows, on average over an
+// episode.  Rows of agents IN the game are built in the wavefront's private LDS staging buffer, `rs`
+// rows at a time in packed order (the wavefront's list of live rows maps the packed ordinal to the
+// row): work item = (live row, neighbour slot) -> 7 values at c*K + k of the row image; then the time
+// column; then every row image leaves as 16-byte write-through stores.
+//   A row image starts `mis` dwords into its slot, mis = (row address / 4) & 3, so that its 16-byte
+// vectors are aligned in LDS and in memory alike (rows are 4 * F bytes, F odd: the alignment changes
+// from row to row); the slot's pads are zeroed.  The <= 3 dwords at either end of a row share a
+// 16-byte line with the neighbouring row:
+//   * neighbour out of the game: its row is (or is being) cleared, so the whole line is stored with
+//     zeros in the neighbour's part;
+//   * neighbour in the game and built in the same chunk (the next slot): the lower row stores the line,
+//     merged (OR) with the first vector of the next slot; the upper row skips its first vector;
+//   * neighbour unknown (other wavefront / other block) or in another chunk: single dwords, own part only.
+__device__ __forceinline__ void tc_store_own_dwords(float *rowp, int F, int d0, const float (&v)[4], bool on) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (on && d0 + e >= 0 && d0 + e < F) rowp[d0 + e] = v[e];
+}
+
+__device__ __forceinline__ void tc_gather_rows_sparse(const TcArgs &a, const TcFastLds &l, const TcTables &tb, float *stage,
+                                               int env0, int wrow0, int wrows, int lane, int K, int N, float invK,
+                                               float invN) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int F = 7 * K + 1;
+  const int SL = (F + 6) & ~3;       // dwords per row slot (mis + F <= SL)
+  const int NV = SL >> 2;            // 16-byte vectors per slot
+  const int cap = l.stage_dwords - 16;
+  const int rs = min(min(64, cap / SL), 192 / K);  // rows per chunk (at most 3 items per lane)
+  const int RPR = 64 / NV;           // rows per flush round (NV <= 58 for K <= 32)
+  const float invNV = 1.0f / (float)NV;
+  constexpr int U = 3;
+  int rr[U], kk[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int t = lane + 64 * u;
+    rr[u] = (int)(((float)t + 0.5f) * invK);  // t / K (exact: the quotient is >= 0.5/K away from an integer)
+    kk[u] = t - rr[u] * K;
+  }
+  const int fsub = (int)(((float)lane + 0.5f) * invNV), fv = lane - fsub * NV;  // flush: (row of the round, vector)
+  const int sgv = (lane < wrows) ? l.sig[wrow0 + lane] : 2;
+  const unsigned long long lmask = __ballot((sgv & 1) != 0);  // rows to build (a wavefront gathers at most 64 rows)
+  unsigned long long zmask = __ballot(sgv == 0);              // rows to clear: out of the game, not cleared yet
+  unsigned char *const rowlist = (unsigned char *)(stage + cap);
+  if (sgv & 1) rowlist[__popcll(lmask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  float *const obs_w = a.obs + ((long)env0 * N + wrow0) * F;
+  const unsigned bdw = (unsigned)((size_t)obs_w >> 2);
+  const unsigned short *const idw = l.ids + (size_t)wrow0 * K;
+  const TcFeat *const fw = l.feat + wrow0;
+  const int n_rows = __popcll(lmask);
+  // ---- rows of agents that left the game since the last tick: zeros, straight from registers
+  while (zmask) {  // wave-uniform, rare
+    const int r = __ffsll((long long)zmask) - 1;
+    zmask &= zmask - 1ull;
+    float *const rowp = obs_w + (long)r * F;
+    const int mis = (int)((bdw + (unsigned)(r * F)) & 3u);
+    const int d0 = 4 * lane - mis;
+    const float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < NV) {
+      if (d0 >= 0 && d0 + 4 <= F) {
+        const v4f q = {0.0f, 0.0f, 0.0f, 0.0f};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rowp + d0), "v"(q) : "memory");
+      } else {
+        tc_store_own_dwords(rowp, F, d0, z, true);
+      }
+    }
+  }
+  // ---- rows of agents in the game
+  for (int j0 = 0; j0 < n_rows; j0 += rs) {
+    const int rc = min(rs, n_rows - j0);
+    const int items = rc * K;
+    if (lane < rc) {  // zero the pads of the slot (first vector, last two vectors)
+      const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      v4f *const sl = (v4f *)(stage + lane * SL);
+      sl[0] = zero;
+      sl[NV - 2] = zero;
+      sl[NV - 1] = zero;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (64 * u < items) {  // wave-uniform
+        if (lane + 64 * u < items) {
+          const int r = rowlist[j0 + rr[u]];  // row of the item inside the wavefront's rows
+          const unsigned jq = idw[r * K + kk[u]];
+          const TcFeat *const mp = fw + r;
+          const TcFeat me = *mp;
+          // no neighbour in this slot: the agent's own record stands in, so every difference
+          // below is +0.0 without a select
+          const bool valid = (jq != 0xffffu);
+          const TcFeat nb = *(valid ? l.feat + jq : mp);
+          unsigned mv = valid ? 0xffffffffu : 0u;
+          asm volatile("" : "+v"(mv));  // (opaque: keeps the AND below from being turned into selects)
+          const unsigned ts = (unsigned)nb.type_sig & mv;
+          const int mis = (int)((bdw + (unsigned)(r * F)) & 3u);
+          float *o = stage + rr[u] * SL + mis + kk[u];
+          o[0] = (float)(nb.nx - me.nx);   // float64 difference, narrowed (:560)
+          o[K] = (float)(nb.ny - me.ny);
+          o[2 * K] = nb.nsp - me.nsp;      // float32 operands: the float64 difference rounds to this
+          o[3 * K] = nb.nac - me.nac;
+          o[4 * K] = nb.ndir - me.ndir;
+          o[5 * K] = __uint_as_float(ts & 0x3f800000u);
+          o[6 * K] = __uint_as_float((0u - (ts & 1u)) & 0x3f800000u);
+        }
+      }
+    }
+    if (lane < rc) {
+      // time column: float(t) / episode_length (agents in the game, :474,:493,:543)
+      const int r = rowlist[j0 + lane];
+      const int e_m = (int)(((float)(wrow0 + r) + 0.5f) * invN);
+      const int mis = (int)((bdw + (unsigned)(r * F)) & 3u);
+      stage[lane * SL + mis + 7 * K] = tb.tfrac[e_m];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- flush: RPR rows per round, lane = (row of the round, 16-byte vector of its slot); three rounds
+    // per trip so that three independent chains of LDS reads are in flight
+    for (int sb = 0; sb < rc; sb += 3 * RPR) {
+      constexpr int W = 3;
+      int slot[W], r[W], d0[W];
+      bool on[W];
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        slot[u] = sb + u * RPR + fsub;
+        on[u] = (fsub < RPR) && (slot[u] < rc);
+        slot[u] = min(slot[u], rc - 1);
+        r[u] = rowlist[j0 + slot[u]];
+      }
+      v4f q[W], nx[W];
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        const int mis = (int)((bdw + (unsigned)(r[u] * F)) & 3u);
+        d0[u] = 4 * fv - mis;  // row-relative index of the vector's first dword
+        q[u] = *(const v4f *)(stage + slot[u] * SL + 4 * fv);
+        nx[u] = *(const v4f *)(stage + min(slot[u] + 1, rc - 1) * SL);  // first vector of the next slot (merge)
+      }
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        if (sb + u * RPR < rc) {  // wave-uniform
+          float *const rowp = obs_w + (long)r[u] * F;
+          const bool head_part = on[u] && (d0[u] < 0), tail_part = on[u] && (d0[u] < F) && (d0[u] + 4 > F);
+          // the neighbouring rows: in the game?  known at all (inside this wavefront's rows)?
+          const bool prev_known = (r[u] > 0), next_known = (r[u] + 1 < wrows);
+          const bool prev_live = prev_known && ((lmask >> (r[u] - 1)) & 1ull);
+          const bool next_live = next_known && ((lmask >> (r[u] + 1)) & 1ull);
+          const bool merge_next = tail_part && next_live && (slot[u] + 1 < rc);
+          unsigned mm = merge_next ? 0xffffffffu : 0u;
+          asm volatile("" : "+v"(mm));  // (AND mask, not four selects)
+          v4f o = q[u];
+          o.x = __uint_as_float(__float_as_uint(o.x) | (__float_as_uint(nx[u].x) & mm));
+          o.y = __uint_as_float(__float_as_uint(o.y) | (__float_as_uint(nx[u].y) & mm));
+          o.z = __uint_as_float(__float_as_uint(o.z) | (__float_as_uint(nx[u].z) & mm));
+          o.w = __uint_as_float(__float_as_uint(o.w) | (__float_as_uint(nx[u].w) & mm));
+          const bool skip = head_part && prev_live && (slot[u] > 0);            // stored by the row below
+          const bool own_only = (head_part && !skip && (prev_live || !prev_known)) ||
+                                (tail_part && !merge_next && (next_live || !next_known));
+          const bool full = on[u] && (d0[u] < F) && !skip && !own_only;
+          if (full) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rowp + d0[u]), "v"(o) : "memory");
+          if (__ballot(own_only) != 0ull) {  // wave-uniform: a row at the edge of the wavefront's rows or of the chunk
+            const float vals[4] = {o.x, o.y, o.z, o.w};
+            tc_store_own_dwords(rowp, F, d0[u], vals, own_only);
+          }
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 
 // EXACTK: K == KMAX, known at compile time (row offsets become immediates, the K-dependent selects fold away)
 template <int KMAX, bool FUSED, bool EXACTK, int IDB>
@@ -1021,7 +1202,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // experiments/README.md).
   __builtin_amdgcn_s_setprio(3);
   TcIn in;
-  tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn);
+  tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn, true);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
   const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds, in);
   if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
@@ -1070,7 +1251,10 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       if (ag == 0) l.cid[0] = -1;
     }
     l.feat[li] = m.ft;
-    l.sig[li] = sg;
+    // bit 0: in the game before this tick's tagging; bit 1: the observation row in HBM is all zeros already
+    l.sig[li] = (sg ? 1 : 0) | (in.cleared ? 2 : 0);
+    // after this tick's gather (either form) the row of an agent out of the game is zeros, the row of one in it is not
+    if ((in.cleared != 0) != (sg == 0)) a.obs_rows_cleared[gi] = sg ? 0 : 1;
     l.tagcnt[li] = 0;
     if (ag == 0) {
       const int t = in.tstep + 1;  // :800
@@ -1160,7 +1344,11 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // nearest_neighbor_ids [E, N, K]: this wavefront's rows, straight from the 16-bit LDS copies
   tc_flush_ids(l.ids + (size_t)wrow0 * K, a.nearest_ids + ((long)env0 * N + wrow0) * K, wrows * K, lane, wrow0, N,
                invK, invN, epb == 1);
-  {
+  // the sparse form pays when few rows are live (late in an episode); wave-uniform choice
+  const int n_live_rows = __popcll(__ballot(lane < wrows && (l.sig[wrow0 + lane] & 1)));
+  if (n_live_rows * 16 <= wrows * 9) {
+    tc_gather_rows_sparse(a, l, tb, stage, env0, wrow0, wrows, lane, K, N, invK, invN);
+  } else {
     // observation rows, R rows per chunk: work item = (row, neighbour slot) -> 7 values at
     // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run.
     // A chunk holds at most 192 items (tc_stage_rows), i.e. at most 3 per lane; their (row, slot)
@@ -1225,7 +1413,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         // time column: float(t) / episode_length for agents in the game, else 0 (:474,:493,:543)
         const int m = wrow0 + r0 + lane;
         const int e_m = (int)(((float)m + 0.5f) * invN);
-        stage[mis + lane * F + 7 * K] = (l.sig[m] != 0) ? tb.tfrac[e_m] : 0.0f;
+        stage[mis + lane * F + 7 * K] = (l.sig[m] & 1) ? tb.tfrac[e_m] : 0.0f;
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -1494,7 +1682,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
       int *num_runners_arr, float kDistanceMarginForReward, float kTagRewardForTagger,            \
       float kTagPenaltyForRunner, float kEndOfGameRewardForRunner, int *done_arr,                 \
       int *env_timestep_arr, int kNumAgents, int kEpisodeLength, int kNumEnvs,                    \
-      int kNumAccelerationActions, int kNumTurnActions, int kEnvBegin
+      int kNumAccelerationActions, int kNumTurnActions, int *obs_rows_cleared_arr, int kEnvBegin
 
 #define WD_TC_PACK()                                                                              \
   TcArgs a;                                                                                       \
@@ -1510,7 +1698,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   a.margin = kDistanceMarginForReward; a.tag_reward = kTagRewardForTagger;                        \
   a.tag_penalty = kTagPenaltyForRunner; a.end_reward = kEndOfGameRewardForRunner;                 \
   a.done = done_arr; a.timestep = env_timestep_arr; a.N = kNumAgents; a.T = kEpisodeLength;       \
-  a.E = kNumEnvs; a.env_begin = kEnvBegin;                                                        \
+  a.E = kNumEnvs; a.env_begin = kEnvBegin; a.obs_rows_cleared = obs_rows_cleared_arr;              \
   (void)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
 
 // Fused rollout tick: sample both action heads + step + reset finished replicas in ONE launch

@@ -270,6 +270,11 @@ class TagContinuous(CUDAEnvironmentContext):
         feed.add_data(name="neighbor_ids_sorted_by_distance", data=np.zeros((1,), dtype=np.int32))
         feed.add_data(name="nearest_neighbor_ids", data=np.zeros((n, K), dtype=np.int32),
                       save_copy_and_apply_at_reset=True)
+        # 1 = the agent's observation row in HBM is all zeros already (it left the game on an earlier tick):
+        # rows of agents out of the game stay zero until the episode restarts, so the sparse form of the row
+        # gather clears them once instead of rewriting them every tick (device-side bookkeeping; restored with
+        # the other arrays at a reset)
+        feed.add_data(name="obs_rows_cleared", data=np.zeros((n,), dtype=np.int32), save_copy_and_apply_at_reset=True)
         feed.add_data(name="runner_exits_game_after_tagged", data=self.runner_exits_game_after_tagged)
         feed.add_data(name="still_in_the_game", data=self.still_in_the_game, save_copy_and_apply_at_reset=True)
         return feed
@@ -282,7 +287,7 @@ class TagContinuous(CUDAEnvironmentContext):
         "nearest_neighbor_ids", _REWARDS, "step_rewards", "num_runners", "distance_margin_for_reward",
         "tag_reward_for_tagger", "tag_penalty_for_runner", "end_of_game_reward_for_runner", "_done_",
         "_timestep_", ("n_agents", "meta"), ("episode_length", "meta"), ("n_envs", "meta"),
-        "num_acceleration_actions", "num_turn_actions",
+        "num_acceleration_actions", "num_turn_actions", "obs_rows_cleared",
     ]  # + kEnvBegin appended by step_launch / tick_launch
 
     FAST_PATH_MAX_AGENTS = 512   # tc_fast_impl: blocks of up to 512 threads (9 id bits in the search keys beyond 128 agents)
@@ -316,7 +321,7 @@ class TagContinuous(CUDAEnvironmentContext):
             F = 7 * K + 1
             n_waves = ((A if threads is None else threads) + 63) // 64
             stage_rows = max(1, min(64, (self.STAGE_TARGET_BYTES // 2 if n_waves > 4 else self.STAGE_TARGET_BYTES) // (4 * F)))
-            stage_dwords = align16(4 * stage_rows * F) // 4 + 4
+            stage_dwords = align16(4 * stage_rows * F) // 4 + 4 + 16   # row images + the list of live rows
             area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
             if epb == 1:  # packed positions of the agents in the game + the packed-index -> id table
                 area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(2 * (N + 1))
