@@ -308,3 +308,13 @@ SETS["fixgeom"] = {
     "fixgeom": _FIXGEOM,
     "nofetch_clean": _NOFETCH_CLEAN,
 }
+
+
+# ---- round 3: density threshold of the hybrid row gather (product: sparse form when live rows <= 9/16)
+_THR = "  if (n_live_rows * 16 <= wrows * 9) {"
+SETS["hybrid_thr"] = {
+    "thr9": [],
+    "thr7": [(TC, _THR, "  if (n_live_rows * 16 <= wrows * 7) {")],
+    "thr11": [(TC, _THR, "  if (n_live_rows * 16 <= wrows * 11) {")],
+    "thr0_dense_only": [(TC, _THR, "  if (n_live_rows < 0) {")],
+}
