@@ -42,7 +42,8 @@
 //       gather   the block's rows are split evenly over its wavefronts; each WAVEFRONT turns its rows
 //                into observation rows inside a private LDS staging buffer, a chunk of rows at a
 //                time, and streams every chunk out as one contiguous run of write-through 16-byte
-//                stores (the [E, N, F] layout makes a replica's rows contiguous);
+//                stores (the [E, N, F] layout makes a replica's rows contiguous); a wavefront with at most
+//                9/16 of its rows live builds and stores the live rows only (tc_gather_rows_sparse);
 //       rewards  tag counts -> rewards in the CPU's add order, done flags;
 //       reset    (fused tick) finished replicas are restored in place from the registered
 //                `*_at_reset` copies.
