@@ -43,7 +43,8 @@ def _worker(rank, world, port, total_envs, out_dir):
     np.save(os.path.join(out_dir, f"x_{rank}.npy"), np.stack(xs))
     with open(os.path.join(out_dir, f"r_{rank}.json"), "w") as f:
         json.dump({"first": first, "count": count, "agg": agg, "seed": wdd.rank_seed(274880, r),
-                   "max_t": wdd.max_over_ranks(elapsed)}, f)
+                   "max_t": wdd.max_over_ranks(elapsed), "per_rank": wdd.gather_floats(elapsed),
+                   "allreduce_us": wdd.time_allreduce(190550, 5)}, f)
     wdd.shutdown()
 
 
@@ -55,6 +56,8 @@ def test_two_rank_sharding(tmp_path):
     assert [r["seed"] for r in recs] == [274880, 274881]
     for r in recs:
         assert r["max_t"] == 2.0 and abs(r["agg"] - 7 * 12 / 2.0) < 1e-9
+        # what bench.py adds to its N > 1 line: every rank's own time, and the gradient bucket's all-reduce time
+        assert r["per_rank"] == [1.0, 2.0] and r["allreduce_us"] > 0
     # sharded result == unsharded result: replicas are independent, no collective needed
     from warp_drive_amd.envs.tag_gridworld import TagGridWorld
 
@@ -132,3 +135,34 @@ def test_bench_starts_its_own_ranks():
                           "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0
     assert "bench.py needs an MI355X" in out.stderr and "but WORLD_SIZE" not in out.stderr
+
+
+def test_valu_roofline_from_a_pmc_file(tmp_path, monkeypatch):
+    """bench.py's second roofline: the VALU issue time of a launch from per-class instruction counts (PMC file keyed by
+    the code object's sha256) and the per-class issue rates; None unless kernel, shape and code object match."""
+    import hashlib
+    import json as js
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from warp_drive_amd.managers import hip_driver
+
+    hsaco = tmp_path / "k.hsaco"
+    hsaco.write_bytes(b"code object")
+    monkeypatch.setattr(hip_driver, "HSACO_PATH", str(hsaco))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    counters = {"SQ_WAVES": 4000.0, "SQ_INSTS_VALU": 4000.0 * 100, "SQ_INSTS_VALU_INT32": 4000.0 * 40,
+                "SQ_INSTS_VALU_ADD_F32": 4000.0 * 20, "SQ_INSTS_VALU_FMA_F32": 4000.0 * 10, "SQ_THREAD_CYCLES_VALU": 4000.0 * 100 * 48}
+    rec = {"kernel": "HipTagContinuousTick_K10", "num_envs": 2000, "full_obs": False,
+           "hsaco_sha256": hashlib.sha256(b"code object").hexdigest(), "counters_per_launch": counters, "shader_clock_ghz": 2.0}
+    js.dump(rec, open(tmp_path / "profiles" / "pmc_mix.json", "w"))
+    r = bench.valu_roofline("HipTagContinuousTick_K10", 2000, False, 10.0)
+    cycles = 4000 * (40 * 2.9 + 20 * 1.2 + 10 * 2.0 + 30 * 2.5)  # the unclassified 30 are "OTHER"
+    assert abs(r["issue_bound_us"] - cycles / 1024 / 2000.0) < 1e-9 and abs(r["frac"] - r["issue_bound_us"] / 10.0) < 1e-12
+    assert r["wave_insts"] == 100 and r["active_lanes_per_inst"] == 48
+    assert bench.valu_roofline("HipTagContinuousTick_K10", 8000, False, 10.0) is None   # other shape
+    hsaco.write_bytes(b"another code object")
+    assert bench.valu_roofline("HipTagContinuousTick_K10", 2000, False, 10.0) is None   # other code object
