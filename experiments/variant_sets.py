@@ -110,7 +110,7 @@ def _prio2(p_head, p_a, p_bc, p_g):
     ]
 
 
-SETS["prio2"] = {
+SETS_RETIRED_prio2 = {
     "p3211": [],
     "p3210": _prio2(3, 2, 1, 0),
     "p3321": _prio2(3, 3, 2, 1),
@@ -122,7 +122,7 @@ SETS["prio2"] = {
 
 
 # ---- code size: the K-specialised entry points hold two copies of the fast path (K == KM folded / runtime K)
-SETS["codesize"] = {
+SETS_RETIRED_codesize = {
     "base": [],
     "exact_only": [
         (TC, "    else tc_fast_impl<KM, false, false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \\\n", ""),
@@ -265,7 +265,7 @@ _WT_DEF = ('#define WD_TC_STORE_WT(ptr, val) asm volatile("global_store_dwordx4 
 _NOSTORE = [(TC, _WT_DEF, '#define WD_TC_STORE_WT(ptr, val) asm volatile("" ::"v"(ptr), "v"(val) : "memory")')]
 _NOFETCH = [(TC, "  if (FUSED) {\n    // this wavefront's rows of both probability slabs -> LDS",
              "  if (false) {\n    // this wavefront's rows of both probability slabs -> LDS")]
-_KNN_CALL = "    if (!tc_knn_packed<KMAX>(l.xy + el * NP, ag, N, K, nid, rank, in_order)) {"
+_KNN_CALL = "    if (!tc_knn_packed<KMAX, IDB>(sxy, ag, n_cand, K, nid, rank, in_order)) {"
 _NOCHAIN = [(TC, _KNN_CALL,
              "    if (!([&]() {\n#pragma unroll\n      for (int k = 0; k < KMAX; ++k) { const int j = ag + k + 1; nid[k] = j >= N ? j - N : j; }\n"
              "      return true; })()) {")]
@@ -297,8 +297,8 @@ SETS["whatif"] = {
 _FIXGEOM = [
     (TC, "  const int N = a.N, K = EXACTK ? KMAX : a.K;\n  const int F = 7 * K + 1;\n  const int tid = threadIdx.x, T_ = blockDim.x;\n  const int epb = max(1, T_ / N);",
      "  const int N = 105, K = EXACTK ? KMAX : a.K;\n  const int F = 7 * K + 1;\n  const int tid = threadIdx.x, T_ = 128;\n  const int epb = 1;"),
-    (TC, "tc_fast_impl<KM, true, true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions)",
-     "tc_fast_impl<KM, true, true>(a, fz, tc_smem, 21, 21)"),
+    (TC, "tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions)",
+     "tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, 21, 21)"),
 ]
 _NOFETCH_CLEAN = [(TC, "  if (FUSED) {\n    // this wavefront's rows of both probability slabs -> LDS",
                    "  if (FUSED) { for (int i_ = tid; i_ < epb * N * n_acc; i_ += blockDim.x) { slab_acc[i_] = 1.0f / 21.0f; slab_turn[i_] = 1.0f / 21.0f; } }\n"
