@@ -152,8 +152,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
-                    help="Cartpole only: env ticks fused into one launch (fixed-policy rollout; SURVEY 8(d) "
-                         "asks the ceiling run to fuse T ticks); a bench 'step' is then one launch = T ticks")
+                    help="Cartpole / TagGridWorld: env ticks fused into one launch, every tick recorded in batch tensors "
+                         "(fixed-policy rollout; SURVEY 8(d) asks the ceiling run to fuse T ticks); a bench 'step' is "
+                         "then one launch = T ticks")
     ap.add_argument("--no-spread", action="store_true", help="skip the four extra repeats of the timed region")
     ap.add_argument("--profile-episodes", type=int, default=0,
                     help="profiler helper: run this many whole episodes of ticks and exit (no timing, no JSON)")
@@ -220,6 +221,13 @@ def main():
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
     rollout_batch = None
+    if args.workload == "tag_gridworld" and args.ticks_per_launch > 1:
+        Tn, dev, Ng = args.ticks_per_launch, torch.device("cuda", device), env_obj.num_agents
+        env_obj.ticks_per_launch = Tn
+        rollout_batch = {"obs": torch.zeros((Tn, E, Ng, 4 * Ng + 1), dtype=torch.float32, device=dev),
+                         "actions": torch.zeros((Tn, E, Ng, 1), dtype=torch.int32, device=dev),
+                         "rewards": torch.zeros((Tn, E, Ng), dtype=torch.float32, device=dev),
+                         "done": torch.zeros((Tn, E), dtype=torch.int32, device=dev)}
     if args.workload == "cartpole" and args.ticks_per_launch > 1:
         # the ceiling run: T ticks per launch, every tick recorded in the trainer's [T, E, ...] batch tensors
         # (distinct addresses per tick: T ticks move T times the bytes)
@@ -342,11 +350,14 @@ def main():
             # a fused tick kernel also reads every head's probabilities and reads+writes the RNG epoch
             bytes_per_env_step += sum(4 * N * a for a in engine.head_sizes) + 8 * N
         bytes_per_launch = bytes_per_env_step * E
-        if rollout_batch is not None:
+        if rollout_batch is not None and args.workload == "cartpole":
             # T ticks per launch with every tick recorded: per env-step 16 B observation + 4 B action + 4 B reward +
             # 4 B done flag written (28 B, distinct addresses), per launch and replica the state in and out, the
             # probabilities, the RNG epoch and the time step (SURVEY 8(d)'s 68 B counted once)
             bytes_per_launch = (28 * engine.ticks_per_launch + bytes_per_env_step) * E
+        elif rollout_batch is not None:
+            # TagGridWorld: per env-step N x (F + 2) floats recorded + the done flag; the per-tick arrays once per launch
+            bytes_per_launch = ((4 * N * (4 * N + 1 + 2) + 4) * engine.ticks_per_launch + bytes_per_env_step) * E
         kern_s = kern_us * 1e-6
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they

@@ -174,3 +174,66 @@ def test_gridworld_fused_tick(full_obs, E):
         np.testing.assert_array_equal(obs_dev[~fin], obs_step[~fin], err_msg=f"t={t}")
         np.testing.assert_array_equal(obs_dev[fin], orc.obs.astype(np.float32)[fin], err_msg=f"t={t}")
     assert finished >= 2 * E
+
+
+@pytest.mark.parametrize("full_obs,E,ticks", [(True, 1000, 16), (False, 77, 9)])
+def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
+    """HipTagGridWorldRollout: T ticks of a fixed-policy rollout in one launch.  Row k of the env-level batch
+    tensors is tick k: the observation the actions were sampled on, the actions (draw for draw: the Philox draw of
+    tick k of T single-tick launches), the rewards and the done flag, replayed through the oracle (integer moves and
+    observations exact, rewards <= 1 ulp as everywhere for this env); finished replicas restart inside the launch;
+    the per-tick arrays hold the state after the last tick."""
+    import torch
+    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from tests.hip_harness import OBS, pull, ulp_diff
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
+    from warp_drive_amd.rollout import RolloutEngine
+
+    cfg = dict(num_taggers=4, grid_length=10, episode_length=23, seed=27, wall_hit_penalty=0.1,
+               tag_reward_for_tagger=10.0, tag_penalty_for_runner=2.0, step_cost_for_tagger=0.01,
+               use_full_observation=full_obs)
+    w = _mk(cfg, E)
+    w.env.ticks_per_launch = ticks
+    N = w.n_agents
+    F = 4 * N + 1 if full_obs else 6
+    sampler = HIPSampler(w.cuda_function_manager)
+    sampler.init_random(seed=5)
+    rng = np.random.RandomState(3)
+    probs = torch.from_numpy(rng.dirichlet(np.ones(5), size=(E, N)).astype(np.float32)).cuda()
+    batch = {"obs": torch.full((ticks, E, N, F), 7.0, device="cuda"),
+             "actions": torch.full((ticks, E, N, 1), -1, dtype=torch.int32, device="cuda"),
+             "rewards": torch.full((ticks, E, N), -1.0, device="cuda"),
+             "done": torch.full((ticks, E), -1, dtype=torch.int32, device="cuda")}
+    engine = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch)
+    assert engine.fused and engine.step_kernel_name == "HipTagGridWorldRollout" and engine.ticks_per_launch == ticks
+    ocfg = dict(cfg)
+    ocfg.pop("seed")
+    orc = TagGridWorldOracle(num_envs=E, **ocfg)
+    rng_words = np.zeros(4 + E * N, dtype=np.uint32)
+    probs_host = probs.cpu().numpy()
+    finished = 0
+    for launch in range(6):
+        drv.memcpy_dtoh(rng_words, sampler.rng_state)
+        torch.cuda.synchronize()
+        assert (rng_words[4:] == launch * ticks).all()
+        engine.run(1)
+        torch.cuda.synchronize()
+        b = {k: v.cpu().numpy() for k, v in batch.items()}
+        for k in range(ticks):
+            np.testing.assert_array_equal(b["obs"][k], orc.obs.astype(np.float32), err_msg=f"obs row {k} of launch {launch}")
+            u, _ = fused_tick_uniforms(E * N, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            a = sample_actions_counting(probs_host, u.reshape(E, N))
+            np.testing.assert_array_equal(b["actions"][k, :, :, 0], a, err_msg=f"actions row {k}")
+            orc.step(a)
+            assert ulp_diff(b["rewards"][k], orc.rewards.astype(np.float32)).max() <= 1
+            np.testing.assert_array_equal(b["done"][k], orc.done, err_msg=f"done row {k}")
+            finished += int((orc.done > 0).sum())
+            last_done = orc.done.copy()
+            orc.reset_done_envs()
+        np.testing.assert_array_equal(pull(w, "loc_x"), orc.loc_x)
+        np.testing.assert_array_equal(pull(w, "loc_y"), orc.loc_y)
+        np.testing.assert_array_equal(pull(w, "_timestep_"), orc.timestep)
+        np.testing.assert_array_equal(pull(w, "_done_"), last_done)
+        np.testing.assert_array_equal(pull(w, OBS), orc.obs.astype(np.float32))
+    assert finished >= 2 * E

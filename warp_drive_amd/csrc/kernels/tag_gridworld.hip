@@ -194,6 +194,162 @@ __device__ __forceinline__ void gw_step_impl(
   }
 }
 
+// ---- T ticks per launch with every tick recorded (fixed-policy rollout).  One tick at 1000 replicas is
+// 0.7 MB and ~4 dependent global round trips: a launch per tick is bound by the kernel boundary (8 us).
+// Here a block keeps its replicas' positions in registers and their observation image in LDS over
+// `ticks` ticks; tick k writes ROW k of the env-level batch tensors obs [T, E, N, F], actions [T, E, N],
+// rewards [T, E, N], done [T, E] -- the observation the action was sampled on, the action (same Philox
+// draw as tick k of T single-tick launches), the reward and the done flag (trainer_base.py:392-426 records
+// exactly these per tick) -- and the per-tick arrays receive the state after the last tick.  A replica that
+// finishes is restored in place from the registered `*_at_reset` copies (reset.cu:9-75) and goes on.
+// Needs the LDS observation image (rows of up to ~60 floats).  n_actions <= 8.
+__device__ __forceinline__ void gw_rollout_impl(
+    int *states_x_arr, int *states_y_arr, int *actions_arr, int *done_arr, float *rewards_arr, float *obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner, float step_cost_for_tagger,
+    int use_full_observation, int world_boundary, int *env_timestep_arr, int episode_length, int n_agents,
+    int n_envs, const GwFuse &fz, int ticks, float *obs_batch, int *action_batch, float *reward_batch,
+    int *done_batch, int *s_mem) {
+  const int N = n_agents;
+  const int epb = max(1, (int)blockDim.x / N);
+  const int A = epb * N;
+  const int F = use_full_observation ? 4 * N + 1 : 6;
+  int *s_x = s_mem;
+  int *s_y = s_x + A;
+  float *s_fx = (float *)(s_y + A);
+  float *s_fy = s_fx + A;
+  int *s_t = (int *)(s_fy + A);
+  int *s_done = s_t + epb;
+  float *s_obs = (float *)(s_done + epb);
+  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int el = tid / N, ag = tid - el * N;
+  const float L = (float)world_boundary;
+  const uint32_t k0 = fz.rng_state[0], k1 = fz.rng_state[1];
+
+  for (int env0 = blockIdx.x * epb; env0 < n_envs; env0 += gridDim.x * epb) {
+    const int env = env0 + el;
+    const bool active = (el < epb) && (env < n_envs);
+    const int idx = env * N + ag;
+    const int li = el * N + ag;
+    const int envs_here = min(epb, n_envs - env0);
+    const int n_out = envs_here * N * F;
+    float *const obs_blk = obs_arr + (long)env0 * N * F;
+    int x = 0, y = 0;
+    uint32_t epoch0 = 0u;
+    float cumv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cumv[i] = 0.0f;
+    if (active) {
+      x = states_x_arr[idx];
+      y = states_y_arr[idx];
+      epoch0 = fz.rng_state[WD_RNG_HEADER + idx];
+      const float *row = fz.probs + (long)idx * fz.n_actions;
+      float cum = 0.0f;  // the running float32 sums of the (fixed) probabilities, once per launch
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < fz.n_actions) cum = (i == 0) ? row[0] : cum + row[i];
+        cumv[i] = cum;
+      }
+      if (ag == 0) s_t[el] = env_timestep_arr[env];
+    }
+    for (int q = tid; q < n_out; q += T_) s_obs[q] = obs_blk[q];  // the observation the first action is sampled on
+    __syncthreads();
+    for (int k = 0; k < ticks; ++k) {
+      const bool last = (k == ticks - 1);
+      // ---- record the observation of this tick (flat, coalesced)
+      float *const brow = obs_batch + ((long)k * n_envs + env0) * N * F;
+      if ((((size_t)brow & 15) | (size_t)(n_out & 3)) == 0) {  // block-uniform: 16-byte vectors (the usual case)
+        for (int q = tid; q < (n_out >> 2); q += T_) ((float4 *)brow)[q] = ((const float4 *)s_obs)[q];
+      } else {
+        for (int q = tid; q < n_out; q += T_) brow[q] = s_obs[q];
+      }
+      float rew = 0.0f;
+      int a = 0;
+      bool fin_mine = false;
+      if (active) {
+        // ---- sample (random.cu:51-85), the draw of tick k of T single-tick launches
+        const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)idx, epoch0 + (uint32_t)k, (uint32_t)fz.stream_tag, 3u}, k0, k1);
+        const float u = wd_u01_open_closed(rnd.x);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cnt += (i < fz.n_actions && cumv[i] < u) ? 1 : 0;
+        a = min(cnt, fz.n_actions - 1);
+        action_batch[(long)k * n_envs * N + idx] = a;
+        // ---- movement :152-173
+        const int ux = x + kIndexToActionArr[2 * a], uy = y + kIndexToActionArr[2 * a + 1];
+        const int cx = min(max(ux, 0), world_boundary), cy = min(max(uy, 0), world_boundary);
+        if (ux != cx || uy != cy) rew = -wall_hit_penalty;
+        x = cx;
+        y = cy;
+        s_x[li] = cx;
+        s_y[li] = cy;
+        s_fx[li] = (float)cx / L;
+        s_fy[li] = (float)cy / L;
+        if (ag == 0) s_t[el] += 1;  // :295
+      }
+      __syncthreads();  // positions and time steps are published; every lane is done reading the old image
+      if (active) {
+        const int *px = s_x + el * N, *py = s_y + el * N;
+        const int rx = px[N - 1], ry = py[N - 1];
+        int tag = 0, best = 0, bd = 0x7fffffff;
+        for (int j = 0; j < N - 1; ++j) {  // tag check :175-178, closest tagger :246-261
+          const int dx = px[j] - rx, dy = py[j] - ry;
+          const int d = dx * dx + dy * dy;
+          tag |= (d == 0);
+          if (d < bd) { bd = d; best = j; }
+        }
+        const int t = s_t[el];
+        const bool fin = (t >= episode_length) || tag;  // :314
+        fin_mine = fin;
+        if (ag == 0) {
+          s_done[el] = fin ? 1 : 0;
+          done_batch[(long)k * n_envs + env] = fin ? 1 : 0;
+          if (last) done_arr[env] = fin ? 1 : 0;
+        }
+        const float base = (ag < N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
+                                        : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
+        reward_batch[(long)k * n_envs * N + idx] = base + rew;
+        if (last) {
+          rewards_arr[idx] = base + rew;
+          actions_arr[idx] = a;
+        }
+        gw_write_row(s_obs + (size_t)li * F, s_fx + el * N, s_fy + el * N, N, ag, best,
+                     (float)t / (float)episode_length, use_full_observation);
+      }
+      // the new image and the done flags are complete; did ANY replica of the block finish?  (block-uniform)
+      if (__syncthreads_or(fin_mine ? 1 : 0) == 0) continue;
+      // ---- restore finished replicas (block-uniform per replica): global arrays, and the copies this block holds
+      for (int e = 0; e < envs_here; ++e) {
+        if (s_done[e] == 0) continue;
+        for (int r = 0; r < fz.n_reset_arrays; ++r) {
+          const GwResetEntry ent = fz.reset_table[r];
+          const long base = (long)(env0 + e) * ent.row_elems;
+          const bool is_obs = (ent.data == (uint32_t *)obs_arr);
+          for (int i = tid; i < ent.row_elems; i += T_) {
+            const uint32_t v = ent.ref[base + i];
+            ent.data[base + i] = v;
+            if (is_obs) s_obs[(size_t)e * N * F + i] = __uint_as_float(v);
+          }
+          if (el == e && active) {
+            if (ent.data == (uint32_t *)states_x_arr) x = (int)ent.ref[base + ag];
+            if (ent.data == (uint32_t *)states_y_arr) y = (int)ent.ref[base + ag];
+          }
+        }
+        if (tid == 0) s_t[e] = 0;
+      }
+      __syncthreads();
+    }
+    // ---- what the launch leaves in the per-tick arrays: the state after its last tick
+    if (active) {
+      states_x_arr[idx] = x;
+      states_y_arr[idx] = y;
+      fz.rng_state[WD_RNG_HEADER + idx] = epoch0 + (uint32_t)ticks;
+      if (ag == 0) env_timestep_arr[env] = s_t[el];
+    }
+    for (int q = tid; q < n_out; q += T_) obs_blk[q] = s_obs[q];
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +383,26 @@ __global__ void HipTagGridWorldTick(
   gw_step_impl<true>(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
                      tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger, use_full_observation,
                      world_boundary, env_timestep_arr, episode_length, n_agents, n_envs, fz, gw_smem);
+}
+
+// T ticks per launch, every tick recorded in env-level batch tensors (see gw_rollout_impl)
+__global__ void HipTagGridWorldRollout(
+    int *states_x_arr, int *states_y_arr, int *actions_arr,
+    int *done_arr, float *rewards_arr, float *obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
+    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    int *env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
+    const float *probs, int n_actions, const void *reset_table, int n_reset_arrays, int stream_tag,
+    int ticks, float *obs_batch, int *action_batch, float *reward_batch, int *done_batch) {
+  extern __shared__ __attribute__((aligned(16))) int gw_smem[];
+  GwFuse fz;
+  fz.rng_state = rng_state; fz.probs = probs; fz.n_actions = n_actions;
+  fz.reset_table = (const GwResetEntry *)reset_table; fz.n_reset_arrays = n_reset_arrays;
+  fz.stream_tag = stream_tag;
+  gw_rollout_impl(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
+                  tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger, use_full_observation,
+                  world_boundary, env_timestep_arr, episode_length, n_agents, n_envs, fz, ticks, obs_batch,
+                  action_batch, reward_batch, done_batch, gw_smem);
 }
 
 }  // extern "C"

@@ -173,22 +173,43 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         epb, block, grid = self._geometry()
         return self.cuda_step, self.cuda_step_function_feed(_STEP_ARGS), block, grid, self.lds_bytes(epb)
 
-    def tick_launch(self, sampler, probabilities, resetter, env_range=None):
+    ticks_per_launch = 1    # > 1 (with batch tensors): fixed-policy rollout, T ticks fused per launch
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None):
         """Fused rollout tick: sample the action + step + reset finished replicas in ONE launch
         (HipTagGridWorldTick).  probabilities = [float32 CUDA tensor [E, N, n_actions]].  `_done_`
-        stays set for replicas that finished on the tick (already reset); the next tick clears it."""
+        stays set for replicas that finished on the tick (already reset); the next tick clears it.
+        With `ticks_per_launch` > 1 and `batch` = {"obs": [T, E, N, F] float32, "actions": [T, E, N, 1] int32,
+        "rewards": [T, E, N] float32, "done": [T, E] int32} (env-level batch tensors, T >= ticks_per_launch) the
+        launch is HipTagGridWorldRollout: T ticks of a fixed-policy rollout, tick k recorded in row k."""
         from warp_drive_amd.managers.function_manager import _stream_tag
 
         assert env_range is None, "replica ranges are a TagContinuous experiment"
         assert len(probabilities) == 1
         fm, dm = self.cuda_function_manager, self.cuda_data_manager
-        name = self.cuda_step.name.replace("Step", "Tick")
+        rollout = batch is not None and int(self.ticks_per_launch) > 1
+        assert rollout or int(self.ticks_per_launch) == 1, "ticks_per_launch > 1 needs the batch tensors"
+        name = self.cuda_step.name.replace("Step", "Rollout" if rollout else "Tick")
         fm.initialize_functions([name])
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         epb, block, grid = self._geometry()
         args = list(self.cuda_step_function_feed(_STEP_ARGS)) + [
             sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0], reset_args[1],
             _stream_tag("tick")]
+        if rollout:
+            import torch
+
+            E, N, T = int(dm.meta_info("n_envs")), self.num_agents, int(self.ticks_per_launch)
+            F = 4 * N + 1 if self.use_full_observation else 6
+            assert int(probabilities[0].shape[-1]) <= 8 and 4 * (4 * epb * N + 2 * epb + epb * N * F) <= 60000, \
+                "the rollout kernel needs the LDS observation image and at most 8 actions"
+            want = {"obs": ((E, N, F), torch.float32), "actions": ((E, N, 1), torch.int32),
+                    "rewards": ((E, N), torch.float32), "done": ((E,), torch.int32)}
+            for key, (shape, dtype) in want.items():
+                t = batch[key]
+                assert t.is_cuda and t.is_contiguous() and t.dtype == dtype and t.shape[0] >= T and \
+                    tuple(t.shape[1:]) == shape, (key, tuple(t.shape), t.dtype)
+            args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"]]
         return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
 
     def step(self, actions=None):
