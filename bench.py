@@ -22,9 +22,13 @@ object carries the whole profile measured in the same run).
 
 The timed region holds the K launches and nothing else (no event records).  The dominant kernel's
 average launch duration (roofline.achieved) is measured with HIP events on the launch stream around
-windows of 10 back-to-back launches, over one whole episode just before and one just after the timed
-region.  `ms_per_step_spread` = min / median / max of five repeats of the timed region at the same place
-of the episode (`value` is the first).
+windows of 25 back-to-back launches, over one whole episode just before and one just after the timed
+region.  `roofline.frac` prices SURVEY's algorithmic bytes; `roofline.frac_moved` the HBM bytes the PMC counters
+saw (`traffic`), `roofline.frac_full_load` the algorithmic bytes at the cost of a tick with every agent in the
+game (the window of the episode profile that starts at the top of an episode).  `--no-tags` sets the tagging
+distance to 0: nobody ever leaves the game, every tick is a full-load tick (the policy-independent worst case).
+`ms_per_step_spread` = min / median / max of five repeats of the timed region at the same place of the
+episode (`value` is the first).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
         (N > 1 without a launcher: bench.py starts its own N ranks through torch.distributed.run)
@@ -149,6 +153,9 @@ def main():
     ap.add_argument("--num-taggers", type=int, default=None, help="TagContinuous: taggers per replica (default 5)")
     ap.add_argument("--mode", choices=("plan", "graph"), default="plan",
                     help="plan: launches replayed from C; graph: hipGraph of 10 ticks")
+    ap.add_argument("--no-tags", action="store_true",
+                    help="TagContinuous: tagging_distance = 0, so no runner is ever tagged and all agents stay in the "
+                         "game for the whole episode: the worst case of the tick, independent of the policy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reset", action="store_true", help="leave reset_when_done_fused out of the tick")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
@@ -199,6 +206,8 @@ def main():
             cfg["num_runners"] = args.num_runners
         if args.num_taggers is not None:
             cfg["num_taggers"] = args.num_taggers
+        if args.no_tags:
+            cfg["tagging_distance"] = 0.0
         E = args.num_envs or 2000
         env_obj = TagContinuous(**cfg)
     elif args.workload == "tag_gridworld":  # BASELINE configs[1]
@@ -337,7 +346,8 @@ def main():
             K = cfg["num_other_agents_observed"]
             bytes_per_env_step = step_algorithmic_bytes(N, K, cfg["use_full_observation"])
             shape = f"{cfg['num_taggers']} taggers x {cfg['num_runners']} runners"
-            label = (("BASELINE configs[2]: " if N == 105 else "") + f"TagContinuous {shape}, "
+            label = (("BASELINE configs[2]: " if N == 105 else "") + ("NO TAGS (tagging_distance 0: every agent "
+                     "stays in the game) " if args.no_tags else "") + f"TagContinuous {shape}, "
                      f"{f'full obs F={7 * (N - 1) + 1}' if args.full_obs else 'partial obs K=10 (F=71)'}")
             metric = f"env steps/sec, TagContinuous {shape}"
         elif args.workload == "tag_gridworld":
@@ -362,20 +372,34 @@ def main():
         achieved = bytes_per_launch / kern_s / 1e9 if kern_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh): only quoted when they
         # were collected on exactly the code object loaded now and at this shape, else null
-        traffic = None
+        traffic, traffic_stale = None, False
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 from warp_drive_amd.managers import hip_driver
 
                 sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
-                recs = [r for r in json.load(open(pmc)).values()
-                        if r.get("kernel") == engine.step_kernel_name and r.get("num_envs") == E
-                        and r.get("full_obs") == bool(args.full_obs) and r.get("hsaco_sha256") == sha]
+                shape_recs = [r for r in json.load(open(pmc)).values()
+                              if r.get("kernel") == engine.step_kernel_name and r.get("num_envs") == E
+                              and r.get("full_obs") == bool(args.full_obs) and N == 105
+                              and bool(r.get("no_tags", False)) == bool(args.no_tags)]
+                recs = [r for r in shape_recs if r.get("hsaco_sha256") == sha]
                 if args.workload == "tag_continuous" and recs:
                     traffic = recs[0].get("hbm_bytes_per_launch")
+                # counters exist for this shape but were collected on another build of the kernels
+                traffic_stale = bool(args.workload == "tag_continuous" and shape_recs and not recs)
             except Exception:
                 traffic = None
+        # the tick with every agent in the game: the window of the episode profile closest to the top of an episode
+        full_load_us = full_load_tick = None
+        if is_tc and args.mode == "plan":
+            starts = [((first_pass_tick + i * WIN) % T, v) for i, v in enumerate(win_us)] + \
+                     [((second_pass_tick + i * WIN) % T, v) for i, v in enumerate(win_us2)]
+            top = [sv for sv in starts if sv[0] < WIN]
+            if top:
+                full_load_tick = min(sv[0] for sv in top)
+                vals = [v for st, v in top if st == full_load_tick]
+                full_load_us = sum(vals) / len(vals)
         out = {
             "metric": metric,
             "value": world * E * steps * engine.ticks_per_launch / elapsed,
@@ -407,7 +431,13 @@ def main():
             "allreduce_us": allreduce_us,
             "roofline": {
                 "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
+                # the same launch duration priced on the bytes the counters saw (rows of agents out of the game are
+                # not rewritten: less than the algorithmic bytes) ...
+                "frac_moved": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if (traffic and kern_s > 0) else None,
+                # ... and the algorithmic bytes at the cost of a tick with every agent in the game
+                "frac_full_load": (bytes_per_launch / (full_load_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if full_load_us else None,
+                "full_load_us": full_load_us, "full_load_window_first_tick": full_load_tick,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_us": kern_s * 1e6,
                 "samples": kern_n,
                 "timing": f"HIP events around windows of {WIN} back-to-back launches, one whole episode "

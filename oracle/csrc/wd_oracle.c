@@ -110,7 +110,7 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
                           const float *turn_actions, const float *skill_levels, int *sig,
                           float *obs, const int *actions, float *rewards,
                           const float *step_rewards, int *num_runners, int *done,
-                          int *timestep) {
+                          int *timestep, int *nearest_ids) {
   const int N = c->n_agents, K = c->num_other_agents_observed;
   const int F = c->use_full_observation ? 7 * (N - 1) + 1 : 7 * K + 1;
   const float two_pi = (float)(2 * M_PI); /* python float, weak-promoted to float32 */
@@ -188,6 +188,9 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
         o[7 * M] = sg[i] ? tfrac : 0.0f;
       } else {
         for (int f = 0; f < F; ++f) o[f] = 0.0f; /* :548 init_obs */
+        /* optional output: the ids the row was built from, -1 = fewer than K others in the game (:422-444) */
+        int *nid = nearest_ids ? nearest_ids + ((size_t)e * N + i) * K : NULL;
+        if (nid) for (int k = 0; k < K; ++k) nid[k] = -1;
         if (!sg[i]) continue;
         /* k nearest among others still in the game, stable by (distance, id) :422-444 */
         int cnt = 0;
@@ -205,6 +208,7 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
         }
         for (int k = 0; k < cnt; ++k) {
           const int j = cid[k];
+          if (nid) nid[k] = j;
           o[0 * K + k] = (float)(nx[j] - nx[i]);
           o[1 * K + k] = (float)(ny[j] - ny[i]);
           o[2 * K + k] = (float)((double)nf[j] - (double)nf[i]);
@@ -247,17 +251,17 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
   free(nx); free(nf); free(cd); free(cid);
 }
 
-void wdo_tc_step(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
+void wdo_tc_step_ids(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
                  float *direction, float *acceleration, const int *agent_types,
                  float *edge_pen, const float *acc_actions, const float *turn_actions,
                  const float *skill_levels, int *sig, float *obs, const int *actions,
                  float *rewards, const float *step_rewards, int *num_runners, int *done,
-                 int *timestep, int n_threads) {
+                 int *timestep, int *nearest_ids, int n_threads) {
   const int E = c->n_envs;
   if (n_threads <= 1) {
     tc_step_range(c, 0, E, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen,
                   acc_actions, turn_actions, skill_levels, sig, obs, actions, rewards,
-                  step_rewards, num_runners, done, timestep);
+                  step_rewards, num_runners, done, timestep, nearest_ids);
     return;
   }
 #ifdef _OPENMP
@@ -267,8 +271,20 @@ void wdo_tc_step(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
     const int e0 = (int)((long)E * b / n_threads), e1 = (int)((long)E * (b + 1) / n_threads);
     tc_step_range(c, e0, e1, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen,
                   acc_actions, turn_actions, skill_levels, sig, obs, actions, rewards,
-                  step_rewards, num_runners, done, timestep);
+                  step_rewards, num_runners, done, timestep, nearest_ids);
   }
+}
+
+/* the same without the neighbour-id output */
+void wdo_tc_step(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
+                 float *direction, float *acceleration, const int *agent_types,
+                 float *edge_pen, const float *acc_actions, const float *turn_actions,
+                 const float *skill_levels, int *sig, float *obs, const int *actions,
+                 float *rewards, const float *step_rewards, int *num_runners, int *done,
+                 int *timestep, int n_threads) {
+  wdo_tc_step_ids(c, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen, acc_actions,
+                  turn_actions, skill_levels, sig, obs, actions, rewards, step_rewards, num_runners, done,
+                  timestep, NULL, n_threads);
 }
 
 /* -------------------------------------------------------- TagGridWorld step */

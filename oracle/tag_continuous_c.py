@@ -45,6 +45,7 @@ class TagContinuousCOracle:
             setattr(self, k, getattr(one, k))
         self._lib = ctypes.CDLL(_build.build())
         self._lib.wdo_tc_step.restype = None
+        self._lib.wdo_tc_step_ids.restype = None
         self._cfg = _Cfg(self.E, self.N, self.T, self.K, int(self.use_full_observation), int(self.runner_exits),
                          float(self.grid_length), float(self.max_speed), float(self.edge_hit_penalty),
                          float(self.distance_margin_for_reward), float(self.tag_reward_for_tagger),
@@ -66,11 +67,19 @@ class TagContinuousCOracle:
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N, 2)
         P = lambda v: v.ctypes.data_as(ctypes.c_void_p)
         self.sig_before = self.sig.copy()  # observations are generated before this tick's tagging (:876)
-        self._lib.wdo_tc_step(ctypes.byref(self._cfg), P(self.loc_x), P(self.loc_y), P(self.speed), P(self.direction),
-                              P(self.acceleration), P(self.agent_types), P(self.edge_pen),
-                              P(self.acceleration_actions), P(self.turn_actions), P(self.skill_levels), P(self.sig),
-                              P(self.obs), P(a), P(self.rewards), P(self.step_rewards), P(self.num_runners),
-                              P(self.done), P(self.timestep), ctypes.c_int(self.n_threads))
+        # nearest_ids [E, N, K]: the ids the observation rows were built from, in the reference's (distance, id)
+        # order (:422-444); -1 = fewer than K others in the game, or the agent itself is out of it
+        if self.use_full_observation:
+            self.nearest_ids, ids_p = None, ctypes.c_void_p(None)
+        else:
+            self.nearest_ids = np.empty((self.E, self.N, self.K), np.int32)
+            ids_p = P(self.nearest_ids)
+        self._lib.wdo_tc_step_ids(ctypes.byref(self._cfg), P(self.loc_x), P(self.loc_y), P(self.speed),
+                                  P(self.direction), P(self.acceleration), P(self.agent_types), P(self.edge_pen),
+                                  P(self.acceleration_actions), P(self.turn_actions), P(self.skill_levels),
+                                  P(self.sig), P(self.obs), P(a), P(self.rewards), P(self.step_rewards),
+                                  P(self.num_runners), P(self.done), P(self.timestep), ids_p,
+                                  ctypes.c_int(self.n_threads))
 
     def reset_done_envs(self):
         """device-side reset semantics, as TagContinuousOracle.reset_done_envs"""

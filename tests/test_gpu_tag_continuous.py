@@ -72,6 +72,24 @@ def _compare(w, orc, tag, stats):
         np.testing.assert_array_equal(ids_dev[m], orc.nearest_ids[m], err_msg=f"nearest_neighbor_ids {tag}")
 
 
+def _check_ids_after_fused_tick(w, ids_ref, in_game, fin, obs_dev, obs_ref, tag):
+    """`nearest_neighbor_ids` [E, N, K] after a fused tick, for every replica that did not finish on it (a
+    finished one was reset in the launch: its array holds the reset copy): rows of agents in the game when
+    the observation was generated carry the reference's (distance, id) order with -1 padding
+    (tag_continuous.py:422-444), rows of agents out of it are all -1.  Rows whose observation differs (counted
+    near-ties) are left to the near-tie check."""
+    from tests.hip_harness import pull
+
+    E, N, K = ids_ref.shape
+    ids_dev = pull(w, "nearest_neighbor_ids").reshape(E, N, K)
+    rows_ok = (obs_dev == obs_ref).all(axis=2) & ~fin[:, None]
+    m = rows_ok & in_game
+    np.testing.assert_array_equal(ids_dev[m], ids_ref[m], err_msg=f"nearest_neighbor_ids {tag}")
+    out = rows_ok & ~in_game
+    assert (ids_dev[out] == -1).all(), f"nearest_neighbor_ids of agents out of the game {tag}"
+    return int(m.sum()), int((ids_ref[m] < 0).sum())
+
+
 def _run_lockstep(cfg, E, ticks, seed, stats=None):
     from tests.hip_harness import OBS, pull, push_actions
 
@@ -286,11 +304,15 @@ def test_fused_tick_kernel(full_obs, acc_levels, turn_levels, runners, K, E):
         fin = orc.done > 0
         finished_total += int(fin.sum())
         obs_before_reset = orc.obs.astype(np.float32).copy()
+        ids_ref = None if full_obs else orc.nearest_ids.copy()
+        in_game = obs_before_reset[..., -1] != 0   # time column: set for agents in the game at observation time
         orc.reset_done_envs()
         for name, attr in STATE:
             np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
         obs_dev = pull(w, OBS)
         np.testing.assert_array_equal(obs_dev[fin], orc.obs.astype(np.float32)[fin])      # reset observation
+        if ids_ref is not None and K <= N - 1:
+            _check_ids_after_fused_tick(w, ids_ref, in_game, fin, obs_dev, obs_before_reset, f"t={t}")
         live = ~fin
         if not np.array_equal(obs_dev[live], obs_before_reset[live]):
             assert not full_obs
@@ -352,7 +374,7 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     orc = TagContinuousCOracle(E, n_threads=min(32, os.cpu_count() or 1), **cfg)
     np.testing.assert_array_equal(pull(w, OBS), orc.obs)
     rng_words = np.zeros(4 + E * N, dtype=np.uint32)
-    near_tie = rows = finished_total = 0
+    near_tie = rows = finished_total = id_rows = 0
     restarts = np.zeros(E, dtype=np.int64)
     for t in range(ticks):
         drv.memcpy_dtoh(rng_words, sampler.rng_state)
@@ -371,11 +393,16 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
         finished_total += int(fin.sum())
         restarts += fin
         obs_before_reset = orc.obs[~fin].copy()
+        obs_all_before_reset = orc.obs.copy()
         orc.reset_done_envs()
         for name, attr in STATE:
             np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
         obs_dev = pull(w, OBS)
         np.testing.assert_array_equal(obs_dev[fin], orc.obs[fin], err_msg=f"reset observation t={t}")
+        if not full_obs:
+            n_id, n_pad = _check_ids_after_fused_tick(w, orc.nearest_ids, orc.sig_before > 0, fin, obs_dev,
+                                                      obs_all_before_reset, f"t={t}")
+            id_rows += n_id
         live = np.flatnonzero(~fin)
         if not np.array_equal(obs_dev[live], obs_before_reset):
             assert not full_obs, f"full-obs mismatch t={t}"
@@ -387,16 +414,15 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     _TOTALS["near_tie_rows"] += near_tie
     _TOTALS["rows"] += rows
     assert restarts.min() >= 2 and finished_total >= 2 * E, (restarts.min(), finished_total)
+    assert full_obs or id_rows > 0.9 * rows * 0.8, (id_rows, rows)  # nearly every in-game row's ids were compared
     assert near_tie <= max(2, rows // 100000), (near_tie, rows)
 
 
-def test_whole_episode_at_the_headline_shape():
-    """The neighbour search runs over the agents still in the game, packed: 105 of them at the start of an
-    episode, fewer than 64 (one wavefront of searchers, the second one skips the search) from about tick 150
-    on, ~27 at tick 500 under a uniform random policy -- and 105 again after the restart.  The fused tick at
-    the BASELINE shape runs a whole 500-tick episode plus the first 60 ticks of the next one with 48
-    replicas; every tick is compared with the C oracle (actions replayed, state / observations / rewards /
-    done / nearest ids exact) and the live-agent count must really sweep the range."""
+def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed):
+    """The fused tick (sample + step + reset in one launch) with the benchmark's uniform policy, every tick
+    compared with the C oracle: sampled actions replayed, then state / observations / rewards / done /
+    nearest_neighbor_ids and the post-reset state.  Returns (mean live agents per tick, id rows compared,
+    padded id entries compared, rows)."""
     import torch
     from oracle.tag_continuous_c import TagContinuousCOracle
     from tests.hip_harness import OBS, REW, pull, require_gpu
@@ -407,18 +433,18 @@ def test_whole_episode_at_the_headline_shape():
     from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 
     require_gpu()
-    E, cfg = 48, dict(BENCH_CFG)
     w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
     w.reset_all_envs()
     sampler = HIPSampler(w.cuda_function_manager)
-    sampler.init_random(seed=99)
+    sampler.init_random(seed=seed)
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
     engine = RolloutEngine(w, sampler)  # uniform probabilities: the benchmark's policy
     assert engine.step_kernel_name == "HipTagContinuousTick_K10"
     orc = TagContinuousCOracle(E, n_threads=min(16, os.cpu_count() or 1), **cfg)
-    live_seen, near_tie, rows = [], 0, 0
-    for t in range(560):
+    N = orc.N
+    live_seen, near_tie, rows, id_rows, id_pads = [], 0, 0, 0, 0
+    for t in range(ticks):
         engine.run(1)
         torch.cuda.synchronize()
         orc.step(pull(w, "sampled_actions"))
@@ -426,24 +452,53 @@ def test_whole_episode_at_the_headline_shape():
         np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")
         fin = orc.done > 0
         obs_before_reset = orc.obs[~fin].copy()
+        obs_all_before_reset = orc.obs.copy()
+        live_seen.append(float(orc.sig_before.sum(axis=1).mean()))
         orc.reset_done_envs()
         for name, attr in STATE:
             np.testing.assert_array_equal(pull(w, name), getattr(orc, attr), err_msg=f"{name} t={t}")
         obs_dev = pull(w, OBS)
         np.testing.assert_array_equal(obs_dev[fin], orc.obs[fin])
+        n_id, n_pad = _check_ids_after_fused_tick(w, orc.nearest_ids, orc.sig_before > 0, fin, obs_dev,
+                                                  obs_all_before_reset, f"t={t}")
+        id_rows += n_id
+        id_pads += n_pad
         live = np.flatnonzero(~fin)
         if not np.array_equal(obs_dev[live], obs_before_reset):
             bad = np.argwhere((obs_dev[live] != obs_before_reset).any(axis=2))
             bad[:, 0] = live[bad[:, 0]]
             assert _near_tie_rows_c(orc, bad), f"obs mismatch that is not a near-tie t={t}: {bad[:5]}"
             near_tie += len(bad)
-        rows += E * 105
-        live_seen.append(float(orc.sig.sum(axis=1).mean()))
+        rows += E * N
     _TOTALS["near_tie_rows"] += near_tie
     _TOTALS["rows"] += rows
     assert near_tie <= 2, near_tie
+    return live_seen, id_rows, id_pads, rows
+
+
+def test_whole_episode_at_the_headline_shape():
+    """The neighbour search runs over the agents still in the game, packed: 105 of them at the start of an
+    episode, fewer than 64 (one wavefront of searchers, the second one skips the search) from about tick 150
+    on, ~27 at tick 500 under a uniform random policy -- and 105 again after the restart.  The fused tick at
+    the BASELINE shape runs a whole 500-tick episode plus the first 60 ticks of the next one with 48
+    replicas; every tick is compared with the C oracle (actions replayed, state / observations / rewards /
+    done / nearest ids exact) and the live-agent count must really sweep the range."""
+    live_seen, id_rows, _, rows = _fused_ticks_vs_c_oracle(dict(BENCH_CFG), 48, 560, 99)
+    assert id_rows > 0.4 * rows, (id_rows, rows)  # the ids of every in-game row were compared (54 of 105 on average)
     # the episode did sweep the packed-search regimes: two wavefronts of searchers, then one, then 105 again
     assert max(live_seen[:20]) > 95 and min(live_seen[400:499]) < 45 and live_seen[505] > 95, (live_seen[:3], live_seen[480:510:5])
+
+
+def test_arena_empties_below_K_agents_at_the_headline_shape():
+    """N = 105 > 64 with FEWER THAN K + 1 agents left in the game: a tagging distance of a fifth of the arena
+    empties it within ~60 ticks (the taggers never leave), so the packed search runs with fewer candidates
+    than neighbour slots, rows are padded with -1 / zeros, most rows belong to agents out of the game, and
+    replicas whose last runner is tagged finish early and restart inside the launch (tag_continuous.py:422-444,
+    :880-883).  130 ticks of a 110-tick episode, every tick against the C oracle incl. nearest_neighbor_ids."""
+    cfg = dict(BENCH_CFG, tagging_distance=0.2, episode_length=110)
+    live_seen, id_rows, id_pads, rows = _fused_ticks_vs_c_oracle(cfg, 40, 130, 7)
+    assert min(live_seen[60:110]) < 14 and live_seen[112] > 95, (live_seen[60:110:10], live_seen[112])
+    assert id_pads > 500, id_pads  # rows with fewer than K others in the game were compared
 
 
 def _push_state(w, **arrays):

@@ -187,6 +187,32 @@ def test_c_step_matches_reference(golden_dir, tag):
             st[k][m] = v
 
 
+@pytest.mark.parametrize("tag", ["test3", "tagheavy", "bench5x100"])
+def test_c_oracle_neighbour_ids_match_the_numpy_oracle(golden_dir, tag):
+    """`TagContinuousCOracle.nearest_ids` (the checker of the device's nearest_neighbor_ids output in the
+    full-size fused-tick tests) against the numpy oracle's k_nearest_neighbors restatement
+    (tag_continuous.py:422-444: stable (distance, id) order, -1 padding) on the reference's recorded action
+    streams -- both oracles replay the reference bit-exactly, so their ids must be identical too."""
+    from oracle.tag_continuous_c import TagContinuousCOracle
+
+    d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
+    E = d["actions"].shape[1]
+    onp = TagContinuousOracle(num_envs=E, **cfg)
+    oc = TagContinuousCOracle(E, n_threads=2, **cfg)
+    padded = 0
+    for t in range(min(d["actions"].shape[0], 60)):
+        onp.step(d["actions"][t])
+        oc.step(d["actions"][t])
+        np.testing.assert_array_equal(oc.obs, onp.obs.astype(f32))
+        in_game = oc.sig_before > 0
+        np.testing.assert_array_equal(oc.nearest_ids[in_game], onp.nearest_ids[in_game], err_msg=f"t={t}")
+        assert (oc.nearest_ids[~in_game] == -1).all()
+        padded += int((oc.nearest_ids[in_game] < 0).sum())
+        onp.reset_done_envs()
+        oc.reset_done_envs()
+    assert padded > 0 or tag != "tagheavy"  # tagheavy: rows with fewer than K others in the game do occur
+
+
 def test_philox_known_answers():
     """Random123's published known-answer vectors for philox4x32-10 (kat_vectors) pin the
     generator the device sampler and its CPU restatement share."""
