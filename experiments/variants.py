@@ -14,6 +14,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +27,8 @@ def build(set_name):
 
     os.makedirs(OUT, exist_ok=True)
     for name, subs in SETS[set_name].items():
-        src = os.path.join(OUT, f"src_{name}")
+        # the patched copy of the sources lives outside the tree (only the code object ships to the GPU box)
+        src = os.path.join(tempfile.gettempdir(), "wd_variants", f"src_{name}")
         shutil.rmtree(src, ignore_errors=True)
         shutil.copytree(wb.KDIR, src)
         flags = [new for fname, old, new in subs if fname is None]  # (None, "flag", "-f...") = extra compiler flag

@@ -176,7 +176,12 @@ def test_gridworld_fused_tick(full_obs, E):
     assert finished >= 2 * E
 
 
-@pytest.mark.parametrize("full_obs,E,ticks", [(True, 1000, 16), (False, 77, 9)])
+@pytest.mark.parametrize("full_obs,E,ticks", [
+    (True, 1000, 16), (False, 77, 9),
+    # 51 replicas per 256-thread block (an ODD count: the tables in front of the LDS observation image are then
+    # 8 bytes past a 16-byte boundary) and a last block of 36 replicas, whose slice is a multiple of 16 bytes
+    # and leaves through the float4 record path
+    (True, 513 * 51 + 36, 4)])
 def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
     """HipTagGridWorldRollout: T ticks of a fixed-policy rollout in one launch.  Row k of the env-level batch
     tensors is tick k: the observation the actions were sampled on, the actions (draw for draw: the Philox draw of
@@ -207,13 +212,15 @@ def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
              "done": torch.full((ticks, E), -1, dtype=torch.int32, device="cuda")}
     engine = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch)
     assert engine.fused and engine.step_kernel_name == "HipTagGridWorldRollout" and engine.ticks_per_launch == ticks
+    if E > 20000:
+        assert w.env._geometry()[0] == 51
     ocfg = dict(cfg)
     ocfg.pop("seed")
     orc = TagGridWorldOracle(num_envs=E, **ocfg)
     rng_words = np.zeros(4 + E * N, dtype=np.uint32)
     probs_host = probs.cpu().numpy()
     finished = 0
-    for launch in range(6):
+    for launch in range(6 if E < 20000 else 12):
         drv.memcpy_dtoh(rng_words, sampler.rng_state)
         torch.cuda.synchronize()
         assert (rng_words[4:] == launch * ticks).all()

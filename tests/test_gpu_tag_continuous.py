@@ -513,6 +513,7 @@ def _push_state(w, **arrays):
             dm.data_on_device_via_torch(name).copy_(torch.from_numpy(v))
         else:
             drv.memcpy_htod(dm.device_data(name), v)
+        dm.invalidate_derived(name)  # (a write that bypasses the manager: bookkeeping derived from the array is void)
     torch.cuda.synchronize()
 
 
@@ -688,3 +689,39 @@ def test_rollout_falls_back_when_the_tick_does_not_fit_lds():
     engine.run(7)
     torch.cuda.synchronize()
     assert pull(w, "_timestep_").max() <= 5 and np.isfinite(pull(w, "loc_x")).all()
+
+
+def test_host_restore_of_state_voids_the_cleared_row_flags():
+    """`obs_rows_cleared` lets the sparse row gather skip rows of agents that left the game; it is only valid
+    while kernels and reset paths are the sole writers of observations / still_in_the_game.  A host restore of the
+    state (`reset_device`, the manager's host -> device refresh) in the middle of an episode -- every agent back in
+    the game, stale zero rows in the observation array -- must void the flags: the next ticks equal the oracle
+    restarted from the same state.  Late-episode regime forced by a large tagging distance (sparse gather)."""
+    from tests.hip_harness import OBS, pull, push_actions
+
+    cfg = dict(BENCH_CFG, tagging_distance=0.2, episode_length=200)
+    E = 6
+    w = _mk(cfg, E)
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    rng = np.random.RandomState(5)
+
+    def tick(t):
+        a = np.stack([rng.randint(0, 21, size=(E, orc.N)), rng.randint(0, 21, size=(E, orc.N))], axis=2)
+        push_actions(w, a)
+        w.step_all_envs()
+        orc.step(a)
+        np.testing.assert_array_equal(pull(w, "still_in_the_game"), orc.sig, err_msg=f"t={t}")
+        np.testing.assert_array_equal(pull(w, OBS), orc.obs.astype(np.float32), err_msg=f"obs t={t}")
+
+    for t in range(40):
+        tick(t)
+    assert orc.sig.sum(axis=1).max() < 50 and pull(w, "obs_rows_cleared").sum() > 0  # the sparse form is in use
+    dm = w.cuda_data_manager
+    for name in ("loc_x", "loc_y", "speed", "direction", "acceleration", "still_in_the_game", "num_runners",
+                 "edge_hit_reward_penalty"):
+        dm.reset_device(name)   # host copies = the start of the episode
+    assert pull(w, "obs_rows_cleared").sum() == 0
+    orc.reset_all()
+    orc.timestep[:] = 40  # (_timestep_ was not restored)
+    for t in range(40, 46):
+        tick(t)

@@ -84,10 +84,10 @@ __device__ __forceinline__ void gw_step_impl(
   float *s_fy = s_fx + A;                       // [A]
   int *s_t = (int *)(s_fy + A);                 // [epb] timestep after increment
   int *s_done = s_t + epb;                      // [epb] replica finished on this tick
-  float *s_obs = (float *)(s_done + epb);       // [A][F] image of the block's observation slice
+  float *s_obs = (float *)(((size_t)(s_done + epb) + 15) & ~(size_t)15);  // [A][F] image of the block's observation slice, 16-byte aligned (host: lds_bytes)
   // very wide rows (N ~ 64 with full observations) do not fit an LDS image: those blocks write their
   // rows straight to HBM.  The host sizes the dynamic LDS with the same rule (lds_bytes()).
-  const bool image = (size_t)4 * ((size_t)4 * A + 2 * epb + (size_t)A * F) <= WD_GW_IMAGE_MAX_BYTES;
+  const bool image = ((((size_t)4 * ((size_t)4 * A + 2 * epb)) + 15) & ~(size_t)15) + (size_t)4 * A * F <= WD_GW_IMAGE_MAX_BYTES;
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const float L = (float)world_boundary;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void gw_rollout_impl(
   float *s_fy = s_fx + A;
   int *s_t = (int *)(s_fy + A);
   int *s_done = s_t + epb;
-  float *s_obs = (float *)(s_done + epb);
+  float *s_obs = (float *)(((size_t)(s_done + epb) + 15) & ~(size_t)15);  // 16-byte aligned: the record path reads it as float4
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const float L = (float)world_boundary;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void gw_rollout_impl(
       const bool last = (k == ticks - 1);
       // ---- record the observation of this tick (flat, coalesced)
       float *const brow = obs_batch + ((long)k * n_envs + env0) * N * F;
-      if ((((size_t)brow & 15) | (size_t)(n_out & 3)) == 0) {  // block-uniform: 16-byte vectors (the usual case)
+      if ((((size_t)brow & 15) | ((size_t)s_obs & 15) | (size_t)(n_out & 3)) == 0) {  // block-uniform: 16-byte vectors (whenever the block's slice is a multiple of 16 bytes)
         for (int q = tid; q < (n_out >> 2); q += T_) ((float4 *)brow)[q] = ((const float4 *)s_obs)[q];
       } else {
         for (int q = tid; q < n_out; q += T_) brow[q] = s_obs[q];

@@ -115,6 +115,10 @@ class EnvWrapper:
         self.cuda_data_manager.push_data_to_device(data)
         self.cuda_data_manager.push_data_to_device(tensors, torch_accessible=True)
         self.cuda_data_manager.push_data_to_device(pools)
+        # device-side bookkeeping an env derives from other arrays (TagContinuous: `obs_rows_cleared` caches which
+        # observation rows are zeros already): a host write to a source array invalidates it
+        for target, sources in getattr(self.env, "derived_device_state", lambda: {})().items():
+            self.cuda_data_manager.register_derived_state(target, sources)
 
     def reset_all_envs(self):
         self.env.timestep = 0

@@ -279,6 +279,12 @@ class TagContinuous(CUDAEnvironmentContext):
         feed.add_data(name="still_in_the_game", data=self.still_in_the_game, save_copy_and_apply_at_reset=True)
         return feed
 
+    def derived_device_state(self):
+        """`obs_rows_cleared` is valid only while the kernels and the reset paths are the sole writers of the
+        observations and of still_in_the_game: a host write to either zero-fills it (EnvWrapper registers this with
+        the data manager; after a direct write through a torch tensor call `dm.invalidate_derived(name)`)."""
+        return {"obs_rows_cleared": (_OBSERVATIONS, _SIG)}
+
     _STEP_ARGS = [
         _LOC_X, _LOC_Y, _SP, _DIR, _ACC, "agent_types", "edge_hit_reward_penalty", "edge_hit_penalty",
         "grid_length", "acceleration_actions", "turn_actions", "max_speed", "num_other_agents_observed",

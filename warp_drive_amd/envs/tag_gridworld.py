@@ -165,8 +165,9 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         timestep / done, and the [epb * N, F] observation image"""
         A = epb * self.num_agents
         F = 4 * self.num_agents + 1 if self.use_full_observation else 6
-        with_image = 4 * (4 * A + 2 * epb + A * F)
-        return with_image if with_image <= 60000 else 4 * (4 * A + 2 * epb)  # WD_GW_IMAGE_MAX_BYTES
+        tables = (4 * (4 * A + 2 * epb) + 15) // 16 * 16   # the image starts 16-byte aligned (read as float4)
+        with_image = tables + 4 * A * F
+        return with_image if with_image <= 60000 else tables  # WD_GW_IMAGE_MAX_BYTES
 
     def step_launch(self):
         """(function, args, block, grid, shared_bytes) of one device step."""

@@ -69,6 +69,7 @@ class CUDADataManager:
         self._log_data_list = []
         self._shape = {}
         self._dtype = {}
+        self._derived = {}  # source array -> arrays derived from it on the device (register_derived_state)
         self.add_meta_info({"n_agents": num_agents, "episode_length": episode_length,
                             "n_envs": num_envs, "blocks_per_env": blocks_per_env})
         self._register_builtin_arrays()
@@ -156,6 +157,27 @@ class CUDADataManager:
                 self._scalar_data_list.append(key)
             else:
                 raise ValueError(f"the data '{key}' needs to be casted to a float, int, list or array")
+
+    # -- device-side state DERIVED from other arrays (no reference counterpart: the reference keeps none)
+    def register_derived_state(self, target: str, sources):
+        """`target` is bookkeeping a kernel derives from the arrays `sources` (e.g. TagContinuous'
+        `obs_rows_cleared`: which observation rows are all zeros already).  Whenever a source is rewritten from
+        the host (`reset_device`, `invalidate_derived`) the target is zero-filled, which for such arrays means
+        "nothing is known": the kernels then recompute."""
+        assert target in self._device_data_pointer, f"{target} is not on the device"
+        for src in sources:
+            self._derived.setdefault(src, [])
+            if target not in self._derived[src]:
+                self._derived[src].append(target)
+
+    def invalidate_derived(self, source: str):
+        """call after writing `source` on the device by other means than this manager (e.g. through the tensor of
+        `data_on_device_via_torch`): zero-fills every array derived from it"""
+        for target in self._derived.get(source, []):
+            self._zero_fill(target)
+
+    def _zero_fill(self, name: str):
+        raise NotImplementedError
 
     def _remember(self, key, arr):
         self._shape[key] = arr.shape
@@ -276,6 +298,15 @@ class HIPDataManager(CUDADataManager):
                 self._device_data_via_torch[key].copy_(torch.from_numpy(host))
             elif host.nbytes:
                 drv.memcpy_htod(self._device_data_pointer[key], host)
+            self.invalidate_derived(key)
+
+    def _zero_fill(self, name: str):
+        if name in self._device_data_via_torch:
+            self._device_data_via_torch[name].zero_()
+            return
+        zeros = np.zeros(self._shape[name], dtype=self._dtype[name])
+        if zeros.nbytes:
+            drv.memcpy_htod(self._device_data_pointer[name], zeros)
 
     def __del__(self):
         for p in getattr(self, "_owned", []):

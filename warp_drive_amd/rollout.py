@@ -27,12 +27,25 @@ _ACTIONS = Constants.ACTIONS
 
 class RolloutEngine:
     def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
-                 rollout_batch=None, rollout_policy=None):
+                 rollout_batch=None, rollout_policy=None, ticks_per_launch=None):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform.  rollout_batch: the trainer's [T, E, ...] batch
         tensors for envs whose tick kernel fuses T ticks per launch and records every tick itself
         (CUDAClassicControlCartPoleEnv.tick_launch); rollout_policy: (packed weights, hidden width) of a small policy
-        that such a kernel evaluates itself on every tick."""
+        that such a kernel evaluates itself on every tick.  ticks_per_launch: env ticks per launch of THIS engine
+        (None = the env object's own `ticks_per_launch` attribute); the env object is left as it was, so another
+        engine on the same wrapper is not affected."""
+        env = env_wrapper.env
+        saved = getattr(env, "ticks_per_launch", 1)
+        if ticks_per_launch is not None:
+            env.ticks_per_launch = int(ticks_per_launch)
+        try:
+            self._build(env_wrapper, sampler, probabilities, reset_done, fused, rollout_batch, rollout_policy)
+        finally:
+            if ticks_per_launch is not None:
+                env.ticks_per_launch = saved
+
+    def _build(self, env_wrapper, sampler, probabilities, reset_done, fused, rollout_batch, rollout_policy):
         assert env_wrapper.env_backend == "hip"
         self.w = env_wrapper
         self.sampler = sampler

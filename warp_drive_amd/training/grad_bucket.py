@@ -23,6 +23,7 @@ class GradientBucket:
             p.grad = self.flat[offset: offset + p.numel()].view_as(p)  # autograd accumulates into the view in place
             offset += p.numel()
         self.collectives = 0  # all-reduces issued so far (tests / metrics)
+        self.reattached = 0   # times a detached .grad had to be put back into the bucket (see _reattach)
 
     @staticmethod
     def _group_active():
@@ -30,14 +31,35 @@ class GradientBucket:
 
     def zero(self):
         """instead of optimizer.zero_grad(): the views must stay attached to the bucket"""
+        self._reattach()
         self.flat.zero_()
 
     def attached(self):
         return all(p.grad is not None and p.grad.data_ptr() >= self.flat.data_ptr()
                    and p.grad.data_ptr() < self.flat.data_ptr() + 4 * self.flat.numel() for p in self.params)
 
+    def _reattach(self):
+        """`optimizer.zero_grad()` (set_to_none=True by default) or any code that replaces a `.grad` detaches it
+        from the bucket; the collective would then average a stale buffer and the ranks would diverge silently
+        (DistributedDataParallel raises in that situation, a plain bucket does not).  A detached gradient is
+        copied into its slice and the view is restored, so the bucket is always what the optimizers see."""
+        if self.attached():
+            return
+        offset = 0
+        for p in self.params:
+            view = self.flat[offset: offset + p.numel()].view_as(p)
+            lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+            if p.grad is None:
+                view.zero_()
+            elif not (lo <= p.grad.data_ptr() < hi):
+                view.copy_(p.grad)
+            p.grad = view
+            offset += p.numel()
+        self.reattached += 1
+
     def all_reduce_mean(self):
         """average the gradients of all policies over the ranks: one collective"""
+        self._reattach()
         if not self._group_active():
             return
         dist.all_reduce(self.flat)

@@ -108,7 +108,7 @@ def _column_sums(g):
     rows = g.shape[0]
     for r in (2000, 2048, 1024, 1000, 800, 512, 500, 400, 256, 250, 200, 128, 100, 64):
         if rows % r == 0 and rows // r >= 16:
-            return g.view(r, rows // r, g.shape[1]).sum(dim=1, dtype=torch.float32).sum(dim=0)
+            return g.reshape(r, rows // r, g.shape[1]).sum(dim=1, dtype=torch.float32).sum(dim=0)  # (reshape: g may be non-contiguous)
     return g.sum(dim=0, dtype=torch.float32)
 
 
@@ -120,7 +120,8 @@ def _weight_grad(g, x):
     if rows >= (1 << 20):
         for sl in (250, 256, 200, 128, 125, 100, 64, 50, 32):
             if rows % sl == 0:
-                part = torch.bmm(g.view(sl, rows // sl, g.shape[1]).transpose(1, 2), x.view(sl, rows // sl, x.shape[1]))
+                part = torch.bmm(g.reshape(sl, rows // sl, g.shape[1]).transpose(1, 2),
+                                 x.reshape(sl, rows // sl, x.shape[1]))
                 return part.sum(dim=0, dtype=torch.float32)
     return (g.t() @ x).float()
 

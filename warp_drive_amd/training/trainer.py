@@ -215,12 +215,12 @@ class Trainer:
             obs_size = flattened_obs_size(env.observation_space[self.policy_map[pol][0]])
             width = rollout_policy_width(self.models[pol], obs_size, env.ROLLOUT_POLICY_WIDTHS)
             if width is not None and len(self.head_sizes) == 1 and self.head_sizes[0] <= 8:
-                env.ticks_per_launch = self.batch_len
                 packed = pack_rollout_policy(self.models[pol]).to(self.device)
                 batch = {"obs": self.batch[pol]["obs"], "actions": self.batch[pol]["actions"],
                          "rewards": self.batch[pol]["rewards"], "done": self.done_batch}
                 self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
-                                            rollout_batch=batch, rollout_policy=(packed, width))
+                                            rollout_batch=batch, rollout_policy=(packed, width),
+                                            ticks_per_launch=self.batch_len)  # (the env object keeps its own setting)
                 self._batch_rollout = {"policy": pol, "packed": packed}
                 self._want_graph = False
 
