@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wavefront phase timeline of the fused TagContinuous tick (variant "prof" of
-experiments/variant_sets.py: s_memtime stamps at the phase boundaries, written through a
-__device__ pointer the harness sets).  Run on the GPU box after `variants.py build profile`:
+experiments/variant_sets.py = the product source built with -DWD_TC_PROBES: shader-clock stamps at the phase
+boundaries + counters of the search's fallbacks, written through a __device__ pointer the harness sets).  Run on the GPU box after `variants.py build profile`:
     python experiments/phase_profile.py [variant-name] [num_envs] [episode tick of the stamped launch]"""
 import os
 import sys
@@ -33,9 +33,10 @@ sampler.init_random(seed=1)
 create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                   push_data_batch_placeholders=False)
 engine = RolloutEngine(w, sampler, fused=True)
+SLOTS = 24
 n_waves = 2 * E
-buf = drv.mem_alloc(n_waves * 16 * 8)
-drv.memset(buf, 0, n_waves * 16 * 8)
+buf = drv.mem_alloc(n_waves * SLOTS * 8)
+drv.memset(buf, 0, n_waves * SLOTS * 8)
 sym, nbytes = w.cuda_function_manager._module.get_global("tc_prof_g")
 drv.memcpy_htod(sym, np.array([int(buf)], dtype=np.uint64))
 engine.run(300)
@@ -48,44 +49,81 @@ engine.run((T_STAMP - 1300) % 500)
 torch.cuda.synchronize()
 live = w.cuda_data_manager.pull_data_from_device("still_in_the_game").sum(axis=1).mean()
 print(f"stamped launch = tick {T_STAMP} of an episode, {live:.1f} agents in the game")
-drv.memset(buf, 0, n_waves * 16 * 8)
+drv.memset(buf, 0, n_waves * SLOTS * 8)
 torch.cuda.synchronize()
 engine.run(1)
 torch.cuda.synchronize()
-raw = np.zeros(n_waves * 16, dtype=np.uint64)
+raw = np.zeros(n_waves * SLOTS, dtype=np.uint64)
 drv.memcpy_dtoh(raw, buf)
 drv.synchronize()
-st = raw.reshape(-1, 16).astype(np.int64)
-fell_back = st[:, 8] > 0
-print(f"wavefronts with a lane outside the in-order exit of the search (exact ranking branch): {fell_back.sum()} of {(st[:, 13] > 0).sum()}")
-searched = st[:, 7] > 0
-print(f"wavefronts that ran the search: {searched.sum()} of {(st[:, 13] > 0).sum()}")
-st[:, 7] = np.where(searched, st[:, 7], st[:, 6])
-st[:, 8] = np.where(fell_back, st[:, 8], st[:, 7])
-names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "knn key chain", "(ranking branch entered)", "knn ids / ranking branch",
-         "ids flushed", "obs gathered+flushed", "barrier3", "rewards/end"]
+st = raw.reshape(-1, SLOTS).astype(np.int64)
+ran = st[:, 15] > 0
+searched = st[:, 9] > 0
+flags = st[:, 18]
+print(f"wavefronts: {ran.sum()}; ran the search: {searched.sum()}; without a bound at the start: {(flags & 0xff > 0).sum()}; "
+      f"list overflow: {((flags >> 8) & 0xff > 0).sum()}; bound check failed: {((flags >> 16) > 0).sum()}; "
+      f"with a lane in the two-pass fallback: {(st[:, 20] > 0).sum()}")
+pre = searched & (st[:, 8] > 0)
+if pre.any():
+    tr = st[pre, 19]
+    print(f"prefiltered wavefronts: {pre.sum()}; pass-2 trips (4 candidates each) mean {tr.mean():.2f} p50 {np.percentile(tr, 50):.0f} "
+          f"p99 {np.percentile(tr, 99):.0f} max {tr.max()}")
+# phases a wavefront skipped inherit the previous stamp (duration 0)
+for k in range(1, 16):
+    st[:, k] = np.where(st[:, k] > 0, st[:, k], st[:, k - 1])
+names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "search: bound", "search: pass 1 (list)",
+         "search: chain (pass 2 / full)", "search: keys resolved", "search: ids, remember", "id rows + barrier + nearest ids flushed",
+         "obs gathered+flushed", "barrier3", "rewards/end"]
 for wv, label in ((0, "wave 0 of each block (64 agents)"), (1, "wave 1 of each block (41 agents)")):
     s = st[wv::2]
-    ok = (s[:, 6] > 0) & (s[:, 13] > 0)
+    ok = (s[:, 6] > 0) & (s[:, 15] > 0)
     s = s[ok]
     print(f"--- {label}: {ok.sum()} waves; mean / p10 / p90 shader cycles per phase")
-    for k in range(1, 14):
+    for k in range(1, 16):
         d = s[:, k] - s[:, k - 1]
-        print(f"  {names[k]:<24} {d.mean():9.0f} {np.percentile(d, 10):9.0f} {np.percentile(d, 90):9.0f}")
-    tot = s[:, 13] - s[:, 0]
-    real = (s[:, 15] - s[:, 14]) * 10.0
+        print(f"  {names[k]:<40} {d.mean():9.0f} {np.percentile(d, 10):9.0f} {np.percentile(d, 90):9.0f}")
+    tot = s[:, 15] - s[:, 0]
+    real = (s[:, 17] - s[:, 16]) * 10.0
     print(f"  total {tot.mean():.0f} cycles = {real.mean() / 1000:.2f} us -> {tot.mean() / real.mean():.3f} GHz")
-s = st[(st[:, 14] > 0) & (st[:, 15] > 0)]
-t0 = s[:, 14].min()
-start, end = (s[:, 14] - t0) / 100.0, (s[:, 15] - t0) / 100.0
+s = st[(st[:, 16] > 0) & (st[:, 17] > 0)]
+t0 = s[:, 16].min()
+start, end = (s[:, 16] - t0) / 100.0, (s[:, 17] - t0) / 100.0
 pc = lambda a: " ".join(f"{np.percentile(a, q):6.2f}" for q in (0, 10, 50, 90, 99, 100))
 print("percentiles 0/10/50/90/99/100 (us): wave start", pc(start), "| wave end", pc(end), "| lifetime", pc(end - start))
 # absolute timeline of the phase boundaries (us since the first wave started), wave 0 only
 s0 = st[0::2]
-s0 = s0[(s0[:, 6] > 0) & (s0[:, 13] > 0)]
-ghz = ((s0[:, 13] - s0[:, 0]) / ((s0[:, 15] - s0[:, 14]) * 10.0)).mean()
-base = (s0[:, 14] - t0) / 100.0
+s0 = s0[(s0[:, 6] > 0) & (s0[:, 15] > 0)]
+ghz = ((s0[:, 15] - s0[:, 0]) / ((s0[:, 17] - s0[:, 16]) * 10.0)).mean()
+base = (s0[:, 16] - t0) / 100.0
 print("phase boundary, us since first wave start (p10 / p50 / p90), wave 0:")
-for k in range(0, 14):
+for k in range(0, 16):
     tk = base + (s0[:, k] - s0[:, 0]) / (ghz * 1000.0)
-    print(f"  {names[k]:<24} {np.percentile(tk, 10):7.2f} {np.percentile(tk, 50):7.2f} {np.percentile(tk, 90):7.2f}")
+    print(f"  {names[k]:<40} {np.percentile(tk, 10):7.2f} {np.percentile(tk, 50):7.2f} {np.percentile(tk, 90):7.2f}")
+
+# ---- placement: which wavefronts share a SIMD (HW_ID / XCC_ID stamped at the start)
+hw = st[:, 21]
+okw = st[:, 15] > 0
+simd_key = ((hw >> 32) & 15) * (1 << 20) + ((hw >> 13) & 7) * (1 << 16) + ((hw >> 12) & 1) * (1 << 12) + ((hw >> 8) & 15) * 16 + ((hw >> 4) & 3)
+role = np.arange(len(st)) % 2   # 0 = wave 0 of its block (the searcher when <= 64 agents are in the game)
+endt = (st[:, 17] - t0) / 100.0
+import collections
+per = collections.defaultdict(list)
+for i in np.nonzero(okw)[0]:
+    per[int(simd_key[i])].append(i)
+n_on = np.array([len(v) for v in per.values()])
+n_w0 = np.array([int((role[v] == 0).sum()) for v in per.values()])
+last = np.array([endt[v].max() for v in per.values()])
+print(f"SIMDs in use: {len(per)}; wavefronts per SIMD: " + " ".join(f"{k}:{(n_on == k).sum()}" for k in sorted(set(n_on))))
+print("wave-0 roles per SIMD (all its wavefronts counted): " + " ".join(f"{k}:{(n_w0 == k).sum()}" for k in sorted(set(n_w0))))
+for k in sorted(set(n_w0)):
+    m = n_w0 == k
+    print(f"  SIMDs with {k} wave-0 roles ({int(n_on[m].mean() * 100) / 100} wavefronts): last wavefront ends at {last[m].mean():6.2f} us (p90 {np.percentile(last[m], 90):6.2f}, max {last[m].max():6.2f})")
+cu_key = simd_key // 4
+percu = collections.defaultdict(list)
+for i in np.nonzero(okw)[0]:
+    percu[int(cu_key[i])].append(i)
+ncu = np.array([len(v) for v in percu.values()])
+lastcu = np.array([endt[v].max() for v in percu.values()])
+print(f"CUs in use: {len(percu)}; wavefronts per CU: " + " ".join(f"{k}:{(ncu == k).sum()}" for k in sorted(set(ncu))))
+for k in sorted(set(ncu)):
+    print(f"  CUs with {k} wavefronts: last wavefront ends at {lastcu[ncu == k].mean():6.2f} us (max {lastcu[ncu == k].max():6.2f})")

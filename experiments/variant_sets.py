@@ -26,35 +26,9 @@ SETS_RETIRED_store_policy = {
     },
 }
 
-# ---- s_memtime stamps per wavefront at the phase boundaries of the fast path (experiments/phase_profile.py)
-_STAMP_DEFS = '''extern "C" { __device__ unsigned long long *tc_prof_g = nullptr; }
-#define TC_SLOT(k) ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k))
-#define TC_STAMP(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[TC_SLOT(k)] = __builtin_readcyclecounter(); } while (0)
-#define TC_STAMP_RT(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[TC_SLOT(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-namespace {
-'''
-PROFILE = [
-    (TC, "namespace {\n\nstruct TcArgs {", _STAMP_DEFS + "\nstruct TcArgs {"),
-    (TC, "  __builtin_amdgcn_s_setprio(3);\n  TcIn in;\n  tc_issue_loads<FUSED>",
-     "  __builtin_amdgcn_s_setprio(3);\n  TC_STAMP_RT(14); TC_STAMP(0);\n  TcIn in;\n  tc_issue_loads<FUSED>"),
-    (TC, "  if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)\n\n  const int env = env0 + el;",
-     "  if (env0 >= a.E) return;\n  TC_STAMP(1);\n  const int env = env0 + el;"),
-    (TC, "  __syncthreads();  // tables are published; every wavefront is done with the slabs\n",
-     "  TC_STAMP(2);\n  __syncthreads();\n  TC_STAMP(3);\n"),
-    (TC, "      tb.nrun[el] = in.nrun;\n    }\n  }\n  __syncthreads();\n\n  // ------------------------------------------------------------ tags",
-     "      tb.nrun[el] = in.nrun;\n    }\n  }\n  TC_STAMP(4);\n  __syncthreads();\n  TC_STAMP(5);\n  // ---- tags"),
-    (TC, "  // ------------------------------------------------------------ search\n  int nid[KMAX + 1], rank[KMAX + 1];",
-     "  TC_STAMP(6);\n  int nid[KMAX + 1], rank[KMAX + 1];"),
-    (TC, "  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry", "  TC_STAMP(7);\n  __builtin_amdgcn_s_setprio(1);\n  // drop the agent's own entry"),
-    # slot 8 is written only by wavefronts in which some lane leaves the in-order exit of the one-pass search
-    (TC, "  in_order = apart;\n  if (!apart) {", "  in_order = apart;\n  if (!apart) {\n    if (tc_prof_g) tc_prof_g[TC_SLOT(8)] = __builtin_readcyclecounter();"),
-    (TC, "  // ------------------------------------------------------------ ids out: block-local 16-bit neighbour",
-     "  TC_STAMP(9);\n  // ---- ids out: block-local 16-bit neighbour"),
-    (TC, "  // the sparse form pays when few rows are live (late in an episode); wave-uniform choice",
-     "  TC_STAMP(10);\n  // the sparse form pays when few rows are live (late in an episode); wave-uniform choice"),
-    (TC, "  __syncthreads();  // every runner's tag is counted\n", "  TC_STAMP(11);\n  __syncthreads();\n  TC_STAMP(12);\n"),
-    (TC, "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n}\n", "      tc_reset_finished(a, fz, tb, env0, epb);\n    }\n  }\n  TC_STAMP(13); TC_STAMP_RT(15);\n}\n"),
-]
+# ---- shader-clock stamps per wavefront at the phase boundaries of the fast path (experiments/phase_profile.py):
+# the probes are in the product source (WD_TC_PROBE*, compiled out by default); the variant only switches them on
+PROFILE = [(None, "flag", "-DWD_TC_PROBES=1")]
 SETS["profile"] = {"prof": PROFILE}
 
 # ---- wave priority by phase: waves in EARLIER phases win VALU arbitration, so laggards catch up and

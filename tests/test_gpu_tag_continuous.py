@@ -497,7 +497,8 @@ def test_arena_empties_below_K_agents_at_the_headline_shape():
     :880-883).  130 ticks of a 110-tick episode, every tick against the C oracle incl. nearest_neighbor_ids."""
     cfg = dict(BENCH_CFG, tagging_distance=0.2, episode_length=110)
     live_seen, id_rows, id_pads, rows = _fused_ticks_vs_c_oracle(cfg, 40, 130, 7)
-    assert min(live_seen[60:110]) < 14 and live_seen[112] > 95, (live_seen[60:110:10], live_seen[112])
+    # (tick 110 is the first of the next episode: everybody is back; a fifth of the arena then empties it again fast)
+    assert min(live_seen[60:110]) < 14 and live_seen[110] > 95, (live_seen[60:110:10], live_seen[108:113])
     assert id_pads > 500, id_pads  # rows with fewer than K others in the game were compared
 
 

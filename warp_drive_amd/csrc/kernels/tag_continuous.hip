@@ -55,6 +55,28 @@
 //     full-observation mode).
 #include "wd_common.h"
 
+// Phase probes (experiments/phase_profile.py): compiled out of the product build.  With -DWD_TC_PROBES (variant
+// "prof" of experiments/variant_sets.py) lane 0 of every wavefront of the fast path stamps the shader clock at
+// the phase boundaries into 24 slots per wavefront behind a __device__ pointer the harness sets.
+#ifdef WD_TC_PROBES
+extern "C" { __device__ unsigned long long *tc_prof_g = nullptr; }
+#define WD_TC_SLOT(k) ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 24 + (k))
+#define WD_TC_PROBE(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[WD_TC_SLOT(k)] = __builtin_readcyclecounter(); } while (0)
+#define WD_TC_PROBE_RT(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) tc_prof_g[WD_TC_SLOT(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// a value of the wavefront (any lane may call: wave-uniform values; first active lane writes)
+#define WD_TC_PROBE_VAL(k, v) do { if (tc_prof_g && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) tc_prof_g[WD_TC_SLOT(k)] += (unsigned long long)(v); } while (0)
+// where the wavefront runs: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) | XCC_ID << 32
+#define WD_TC_PROBE_HW(k) do { if ((threadIdx.x & 63) == 0 && tc_prof_g) { unsigned hw_, xcc_;                        \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                    \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                                  \
+    tc_prof_g[WD_TC_SLOT(k)] = (unsigned long long)hw_ | ((unsigned long long)(xcc_ & 15u) << 32); } } while (0)
+#else
+#define WD_TC_PROBE_HW(k)
+#define WD_TC_PROBE(k)
+#define WD_TC_PROBE_RT(k)
+#define WD_TC_PROBE_VAL(k, v)
+#endif
+
 namespace {
 
 struct TcArgs {
@@ -111,6 +133,29 @@ struct __attribute__((aligned(16))) TcFeat {
   float nsp, nac, ndir;
   int type_sig;  // float bits of the agent type (1.0f = tagger, 0) | bit 0: still_in_the_game before tagging
 };
+
+// The fast path keeps the record as two arrays of 16-byte halves: a ds_read_b128 starts on one of the 16 aligned
+// four-bank slots of the 64 LDS banks; records of 32 bytes reach only the 8 even slots (a gather of 64 random
+// neighbours then takes 8 passes), halves of 16 bytes reach all 16 (4 passes, the minimum for 64 lanes).
+struct __attribute__((aligned(16))) TcFeatA { double nx, ny; };
+struct __attribute__((aligned(16))) TcFeatB { float nsp, nac, ndir; int type_sig; };
+struct TcFeatArrays {
+  TcFeatA *a;
+  TcFeatB *b;
+};
+__device__ __forceinline__ TcFeat tc_feat_load(const TcFeatArrays &f, int i) {
+  const TcFeatA ha = f.a[i];
+  const TcFeatB hb = f.b[i];
+  TcFeat r;
+  r.nx = ha.nx; r.ny = ha.ny; r.nsp = hb.nsp; r.nac = hb.nac; r.ndir = hb.ndir; r.type_sig = hb.type_sig;
+  return r;
+}
+__device__ __forceinline__ void tc_feat_store(const TcFeatArrays &f, int i, const TcFeat &v) {
+  TcFeatA ha; ha.nx = v.nx; ha.ny = v.ny;
+  TcFeatB hb; hb.nsp = v.nsp; hb.nac = v.nac; hb.ndir = v.ndir; hb.type_sig = v.type_sig;
+  f.a[i] = ha;
+  f.b[i] = hb;
+}
 
 struct TcCand {
   float d2;
@@ -429,7 +474,10 @@ struct TcP4 {
 // ds_read_b128 with a wave-uniform address -- half the LDS cycles of four 8-byte reads, and the LDS
 // pipe is what bounds pass B otherwise
 __device__ __forceinline__ TcP4 tc_load4(const float2 *cxy, int j) {
-  const float4 a = *(const float4 *)(cxy + j), b = *(const float4 *)(cxy + j + 2);
+  // (j is a multiple of 4 and every replica's positions start 16-byte aligned: say so, or a start index the compiler
+  // cannot see through turns the two ds_read_b128 into eight ds_read_b32)
+  const float4 *const q = (const float4 *)__builtin_assume_aligned(cxy + j, 16);
+  const float4 a = q[0], b = q[1];
   TcP4 r;
   r.p[0] = make_float2(a.x, a.y); r.p[1] = make_float2(a.z, a.w);
   r.p[2] = make_float2(b.x, b.y); r.p[3] = make_float2(b.z, b.w);
@@ -731,18 +779,10 @@ __device__ __forceinline__ unsigned tc_umed3(unsigned a, unsigned b, unsigned c)
   return r;
 }
 
-// nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
-// `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
-// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512 (buckets of 2^IDB ulps of d2;
-// the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
-// at least 2^(IDB-1) - 1 ulps of the float32 distance)
-template <int KMAX, int IDB>
-__device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX + 1],
-                                              int (&rank)[KMAX + 1], bool &in_order) {
+// ---- the insertion chain over the candidates [j0, j1) (j0 a multiple of 4): L = self + K others + the look-ahead entries
+template <int L, int IDB>
+__device__ __forceinline__ void tc_chain_range(const float2 *cxy, float xi, float yi, int j0, int j1, unsigned (&S)[L]) {
   constexpr unsigned IDM = (1u << IDB) - 1u;
-  const float xi = cxy[ag].x, yi = cxy[ag].y;
-  constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
-  unsigned S[L];
 #pragma unroll
   for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
 #define WD_TC_INSERT_KEY(d2v, jv)                                                          \
@@ -751,43 +791,98 @@ __device__ __forceinline__ bool tc_knn_packed(const float2 *cxy, int ag, int N, 
     _Pragma("unroll") for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_); \
     S[0] = min(S[0], key_);                                                                \
   } while (0)
-  {
-    const int ng = N >> 2;
-    TcP4 nxt = tc_load4(cxy, 0);
-    for (int g = 0; g < ng; ++g) {
-      const TcP4 cur = nxt;
-      // the second half of the chain runs at the lowest priority, like the phases after the search
-      // (the caller entered at 2): measured 36.5 -> 35.6 us per tick with 1 here, another 0.2 us with
-      // 0 here and after the search; dropping after 1/8, 1/4 or 3/4 of the candidates, or not at
-      // all, is 0.1 .. 1 us slower
-      if (g == (ng >> 1)) __builtin_amdgcn_s_setprio(0);
-      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;
-        const float d2 = dx * dx + dy * dy;
-        WD_TC_INSERT_KEY(d2, 4 * g + u);
-      }
-    }
-    for (int j = 4 * ng; j < N; ++j) {
-      const float2 pj = cxy[j];
-      const float dx = xi - pj.x, dy = yi - pj.y;
-      const float d2 = dx * dx + dy * dy;
-      WD_TC_INSERT_KEY(d2, j);
-    }
+  const int g0 = j0 >> 2, ng = j1 >> 2;
+  // groups of four candidates, two groups per trip, ping-pong: the positions of one group are in flight while the
+  // other goes through the chain, and no register is copied (a "load the next group, then rotate" loop is what
+  // the optimiser turns back into "load at the top, wait, use" when the start index is not a constant)
+#define WD_TC_INSERT_GROUP(grp, gidx)                                  \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                      \
+    const float dx = xi - (grp).p[u].x, dy = yi - (grp).p[u].y;        \
+    const float d2 = dx * dx + dy * dy;                                \
+    WD_TC_INSERT_KEY(d2, 4 * (gidx) + u);                              \
+  }
+  // the second half of the chain runs at the lowest priority, like the phases after the search
+  // (the caller entered at 2): measured 36.5 -> 35.6 us per tick with 1 here, another 0.2 us with
+  // 0 here and after the search; dropping after 1/8, 1/4 or 3/4 of the candidates, or not at
+  // all, is 0.1 .. 1 us slower
+  const int g_mid = (g0 + ng) >> 1;
+  TcP4 ga = tc_load4(cxy, 4 * g0), gb;
+  int g = g0;
+  for (; g + 2 <= ng; g += 2) {
+    gb = tc_load4(cxy, 4 * g + 4);
+    asm volatile("" ::: "memory");   // (keeps the load above the work below)
+    if (g >= g_mid && g < g_mid + 2) __builtin_amdgcn_s_setprio(0);
+    WD_TC_INSERT_GROUP(ga, g);
+    ga = tc_load4(cxy, 4 * g + 8);   // (the last prefetch lands in the padding behind the replica's positions)
+    asm volatile("" ::: "memory");
+    WD_TC_INSERT_GROUP(gb, g + 1);
+  }
+  if (g < ng) {
+    if (g >= g_mid) __builtin_amdgcn_s_setprio(0);
+    WD_TC_INSERT_GROUP(ga, g);
+  }
+#undef WD_TC_INSERT_GROUP
+  for (int j = max(4 * ng, j0); j < j1; ++j) {
+    const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
+    const float d2 = dx * dx + dy * dy;
+    WD_TC_INSERT_KEY(d2, j);
   }
 #undef WD_TC_INSERT_KEY
-  __builtin_amdgcn_s_setprio(1);
+}
+
+// ---- the L smallest of the union of two ascending lists of L keys (this lane's S and the partner's P), ascending.
+// Both lists are padded to W = 16 (32, 64) entries with 0xffffffff -- still ascending --, then
+// c[k] = min(S[k], P[W-1-k]) are the W smallest of the 2W (an ascending against a descending sequence: the result
+// is bitonic) and a bitonic merge network sorts them: log2(W) x W/2 compare-exchanges (64 min / max for L <= 16)
+// against L x L median-of-three for inserting the partner's keys one by one.  (Padding AFTER the min step would
+// not do: a bitonic sequence followed by maxima is not bitonic.)
+__device__ __forceinline__ void tc_cex(unsigned &a, unsigned &b) {
+  const unsigned lo = min(a, b), hi = max(a, b);
+  a = lo;
+  b = hi;
+}
+template <int L>
+__device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned (&P)[L]) {
+  constexpr int W = (L <= 8) ? 8 : (L <= 16) ? 16 : (L <= 32) ? 32 : 64;
+  unsigned c[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int q = W - 1 - k;  // partner entry
+    c[k] = (k < L && q < L) ? min(S[k], P[q]) : (k < L) ? S[k] : (q < L) ? P[q] : 0xffffffffu;
+  }
+#pragma unroll
+  for (int stride = W / 2; stride >= 1; stride >>= 1)
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      if ((k & stride) == 0) tc_cex(c[k], c[k + stride]);
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = c[k];
+}
+
+// nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
+// `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
+// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512 (buckets of 2^IDB ulps of d2;
+// the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
+// at least 2^(IDB-1) - 1 ulps of the float32 distance)
+// S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
+// agent's own entry (the caller remembers their ids for the next tick's bound)
+template <int KMAX, int IDB, int L>
+__device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K, const unsigned (&S)[L],
+                                                unsigned (&o)[L - 1], int (&nid)[KMAX + 1], int (&rank)[KMAX + 1],
+                                                bool &in_order) {
+  static_assert(L >= KMAX + 3, "self + K others + two look-ahead entries");
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
   // drop the agent's own entry (d2 = 0 exactly: key == ag).  It is the first entry unless a twin with
   // a lower id sits on the same spot.
-  unsigned o[KMAX + 2];
   if (__ballot(S[0] != (unsigned)ag) == 0ull) {  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < KMAX + 2; ++k) o[k] = S[k + 1];
+    for (int k = 0; k < L - 1; ++k) o[k] = S[k + 1];
   } else {
     bool after = false;
 #pragma unroll
-    for (int k = 0; k < KMAX + 2; ++k) {
+    for (int k = 0; k < L - 1; ++k) {
       after = after || (S[k] == (unsigned)ag);
       o[k] = after ? S[k + 1] : S[k];
     }
@@ -948,7 +1043,7 @@ __device__ __forceinline__ int tc_stage_rows(int row_dwords, int n_waves) {
 // LDS of the fast path.  The per-trip area doubles as the two probability slabs of the fused tick,
 // which are dead before the move phase writes it.
 struct TcFastLds {
-  TcFeat *feat;          // [A] observation features
+  TcFeatArrays feat;     // [A] + [A] observation features, two 16-byte halves per agent
   float2 *xy;            // [epb][NP] positions after the move (x = +BIG for agents out of the game); NP = N rounded up
                          // to a multiple of 4, plus 8 entries of padding that the search's prefetches may read
   int *sig;              // [A] still_in_the_game before this tick's tagging
@@ -968,7 +1063,8 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   const size_t A = (size_t)epb * N;
   const int F = 7 * K + 1;
   size_t off = 0;
-  l.feat = (TcFeat *)(p0 + off); off += sizeof(TcFeat) * A;
+  l.feat.a = (TcFeatA *)(p0 + off); off += sizeof(TcFeatA) * A;
+  l.feat.b = (TcFeatB *)(p0 + off); off += sizeof(TcFeatB) * A;
   l.xy = (float2 *)(p0 + off); off += 8 * (size_t)epb * (((N + 3) & ~3) + 8);  // see TcFastLds::xy
   l.sig = (int *)(p0 + off); off += 4 * A;
   l.tagcnt = (int *)(p0 + off); off += 4 * A;
@@ -1040,7 +1136,6 @@ __device__ __forceinline__ void tc_gather_rows_sparse(const TcArgs &a, const TcF
   float *const obs_w = a.obs + ((long)env0 * N + wrow0) * F;
   const unsigned bdw = (unsigned)((size_t)obs_w >> 2);
   const unsigned short *const idw = l.ids + (size_t)wrow0 * K;
-  const TcFeat *const fw = l.feat + wrow0;
   const int n_rows = __popcll(lmask);
   // ---- rows of agents that left the game since the last tick: zeros, straight from registers
   while (zmask) {  // wave-uniform, rare
@@ -1076,12 +1171,11 @@ __device__ __forceinline__ void tc_gather_rows_sparse(const TcArgs &a, const TcF
         if (lane + 64 * u < items) {
           const int r = rowlist[j0 + rr[u]];  // row of the item inside the wavefront's rows
           const unsigned jq = idw[r * K + kk[u]];
-          const TcFeat *const mp = fw + r;
-          const TcFeat me = *mp;
+          const TcFeat me = tc_feat_load(l.feat, wrow0 + r);
           // no neighbour in this slot: the agent's own record stands in, so every difference
           // below is +0.0 without a select
           const bool valid = (jq != 0xffffu);
-          const TcFeat nb = *(valid ? l.feat + jq : mp);
+          const TcFeat nb = tc_feat_load(l.feat, valid ? (int)jq : wrow0 + r);
           unsigned mv = valid ? 0xffffffffu : 0u;
           asm volatile("" : "+v"(mv));  // (opaque: keeps the AND below from being turned into selects)
           const unsigned ts = (unsigned)nb.type_sig & mv;
@@ -1170,7 +1264,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const int F = 7 * K + 1;
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int epb = max(1, T_ / N);
-  const int n_waves = (T_ + 63) >> 6, wave = tid >> 6, lane = tid & 63;
+  // (readfirstlane: the wavefront index is uniform, but only the hardware knows -- without it every loop whose
+  // bounds depend on it is compiled as a divergent loop)
+  const int n_waves = (T_ + 63) >> 6, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
   // One replica per block (more than 64 agents: the BASELINE shape): the neighbour search runs over
   // the agents that are still IN THE GAME only, packed in ascending id order -- as candidates (the
@@ -1202,11 +1298,13 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // two-pass search: 48.6 -> 44.4 us per tick; the schedule was re-tuned for the one-pass search,
   // experiments/README.md).
   __builtin_amdgcn_s_setprio(3);
+  WD_TC_PROBE_RT(16); WD_TC_PROBE(0); WD_TC_PROBE_HW(21);
   TcIn in;
   tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn, true);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
   const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds, in);
   if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
+  WD_TC_PROBE(1);
 
   const int env = env0 + el;
   const bool active = (el < epb) && (env < a.E);
@@ -1220,7 +1318,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
     sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
   }
+  WD_TC_PROBE(2);
   __syncthreads();  // tables are published; every wavefront is done with the slabs
+  WD_TC_PROBE(3);
   // packed index of this lane's agent among the agents in the game, and their number
   int my_c = ag, n_live = N;
   if (compact) {
@@ -1251,7 +1351,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       }
       if (ag == 0) l.cid[0] = -1;
     }
-    l.feat[li] = m.ft;
+    tc_feat_store(l.feat, li, m.ft);
     // bit 0: in the game before this tick's tagging; bit 1: the observation row in HBM is all zeros already
     l.sig[li] = (sg ? 1 : 0) | (in.cleared ? 2 : 0);
     // after this tick's gather (either form) the row of an agent out of the game is zeros, the row of one in it is not
@@ -1265,7 +1365,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       tb.nrun[el] = in.nrun;
     }
   }
+  WD_TC_PROBE(4);
   __syncthreads();
+  WD_TC_PROBE(5);
 
   // ------------------------------------------------------------ tags (counts are read after the
   // barrier that follows the gather)
@@ -1274,6 +1376,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     tagged = tc_find_tag(a, tb, l.xy + el * NP, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
 
   // ------------------------------------------------------------ search
+  WD_TC_PROBE(6);
   int nid[KMAX + 1], rank[KMAX + 1];  // entry k is one of the K nearest iff rank[k] < K
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) { nid[k] = -1; rank[k] = k; }
@@ -1286,10 +1389,49 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const float2 *const sxy = compact ? l.xyc : l.xy + el * NP;
   const int n_cand = compact ? n_live : N;
   int row_agent = ag;  // the agent whose row this lane's search fills
+  // TWO WAVEFRONTS PER SEARCHER while at most 64 agents are in the game (70 % of an episode of the benchmark
+  // policy): the searchers then fit the first wavefront and the second one used to wait at the barrier below for
+  // the whole search -- with two of the four wavefronts of a SIMD idle the chain is bound by the issue latency of a
+  // single wavefront (~10 cycles per instruction), not by the VALU.  Now lane i of BOTH wavefronts works for searcher
+  // i: wavefront 0 runs the chain over the first half of the candidates, wavefront 1 over the second half; wavefront
+  // 1 hands its L keys over through its staging buffer (dead until the gather) and wavefront 0 merges the two sorted
+  // lists (tc_merge_sorted: the L smallest of the union are exactly what one chain over all candidates keeps).
+  constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
+  const bool split = compact && (n_waves == 2) && (n_live <= 64) && (n_live >= 16) &&
+                     (l.stage_dwords >= 64 * L);                          // block-uniform
+  const int j_half = split ? (((n_live + 7) >> 3) << 2) : n_cand;        // first candidate of wavefront 1's half
+  const bool helper = split && (wave == 1);                               // wave-uniform
+  unsigned S[L];
+  if (searcher || (helper && lane < n_live)) {
+    // one pass with packed keys (this wavefront's share of the candidates)
+    const int me = helper ? lane : ag;
+    tc_chain_range<L, IDB>(sxy, sxy[me].x, sxy[me].y, helper ? j_half : 0, helper ? n_cand : j_half, S);
+  }
+  WD_TC_PROBE(9);
+  if (split) {  // block-uniform
+    if (helper && lane < n_live) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) ((unsigned *)stage)[64 * k + lane] = S[k];
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+    if (searcher) {
+      const unsigned *const theirs = (const unsigned *)(l.stage + (size_t)l.stage_dwords);  // wavefront 1's buffer
+      unsigned P[L];
+#pragma unroll
+      for (int k = 0; k < L; ++k) P[k] = theirs[64 * k + lane];
+      tc_merge_sorted<L>(S, P);
+    }
+  }
   if (searcher) {
-    // one pass with packed keys; a lane with three candidates inside 256 ulps at the cut (~1e-7 per
-    // agent) repeats the search with the two-pass one
-    if (!tc_knn_packed<KMAX, IDB>(sxy, ag, n_cand, K, nid, rank, in_order)) {
+    // a lane with three candidates inside 256 ulps at the cut (~1e-7 per agent) repeats the search with the
+    // two-pass one
+    unsigned o[L - 1];
+    __builtin_amdgcn_s_setprio(1);
+    bool exact = tc_resolve_keys<KMAX, IDB, L>(sxy, ag, K, S, o, nid, rank, in_order);
+    WD_TC_PROBE(10);
+    if (!exact) {
+      WD_TC_PROBE_VAL(20, 1);
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
@@ -1308,6 +1450,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     }
   }
   __builtin_amdgcn_s_setprio(0);
+  WD_TC_PROBE(11);
 
   // ------------------------------------------------------------ ids out: block-local 16-bit neighbour
   // ids per agent row in LDS (0xffff = none), read by the gather and turned into the
@@ -1345,6 +1488,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // nearest_neighbor_ids [E, N, K]: this wavefront's rows, straight from the 16-bit LDS copies
   tc_flush_ids(l.ids + (size_t)wrow0 * K, a.nearest_ids + ((long)env0 * N + wrow0) * K, wrows * K, lane, wrow0, N,
                invK, invN, epb == 1);
+  WD_TC_PROBE(12);
   // the sparse form pays when few rows are live (late in an episode); wave-uniform choice
   const int n_live_rows = __popcll(__ballot(lane < wrows && (l.sig[wrow0 + lane] & 1)));
   if (n_live_rows * 16 <= wrows * 9) {
@@ -1370,7 +1514,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       const int mis = (int)(((size_t)dst >> 2) & 3);
       const int items = rc * K;
       const unsigned short *const idp = l.ids + (size_t)(wrow0 + r0) * K;  // ids of item t: idp[t]
-      const TcFeat *const fp = l.feat + wrow0 + r0;
+      const int fp = wrow0 + r0;
       // ids, then feature records, all reads of a lane's items in flight together.  A lane whose item
       // index is past the end recomputes the LAST item and writes the same values to the same place:
       // straight-line code (exec-mask branches would cost more than the duplicate work)
@@ -1388,12 +1532,11 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         const int r_last = rc - 1, o_last = r_last * F + (K - 1);
         const int r = cl ? r_last : rr[u];
         off[u] = cl ? o_last : so[u];
-        const TcFeat *const mp = fp + r;
-        me[u] = *mp;
+        me[u] = tc_feat_load(l.feat, fp + r);
         // no neighbour (or the agent is out of the game): its own record stands in, so every
         // difference below is +0.0 without a select
         const bool valid = ((me[u].type_sig & 1) != 0) && (jq[u] != 0xffffu);
-        nb[u] = *(valid ? l.feat + jq[u] : mp);
+        nb[u] = tc_feat_load(l.feat, valid ? (int)jq[u] : fp + r);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1423,7 +1566,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       __builtin_amdgcn_wave_barrier();
     }
   }
+  WD_TC_PROBE(13);
   __syncthreads();  // every runner's tag is counted
+  WD_TC_PROBE(14);
 
   // ------------------------------------------------------------ rewards / done
   if (active) tc_finish_agent(a, tb, el, ag, gi, env, sg, is_runner, tagged, l.tagcnt[li], edge_pen, in.step_reward, FUSED);
@@ -1437,6 +1582,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       tc_reset_finished(a, fz, tb, env0, epb);
     }
   }
+  WD_TC_PROBE(15); WD_TC_PROBE_RT(17);
 }
 
 // =====================================================================================
