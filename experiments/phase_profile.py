@@ -62,7 +62,8 @@ searched = st[:, 9] > 0
 flags = st[:, 18]
 print(f"wavefronts: {ran.sum()}; ran the search: {searched.sum()}; without a bound at the start: {(flags & 0xff > 0).sum()}; "
       f"list overflow: {((flags >> 8) & 0xff > 0).sum()}; bound check failed: {((flags >> 16) > 0).sum()}; "
-      f"with a lane in the two-pass fallback: {(st[:, 20] > 0).sum()}")
+      f"with a lane in the two-pass fallback: {(st[:, 20] > 0).sum()}; with a lane whose close pair was settled by one exact compare: "
+      f"{(st[:, 23] > 0).sum()}; with a lane in the full ranking: {(st[:, 22] > 0).sum()}")
 pre = searched & (st[:, 8] > 0)
 if pre.any():
     tr = st[pre, 19]
@@ -127,3 +128,15 @@ lastcu = np.array([endt[v].max() for v in percu.values()])
 print(f"CUs in use: {len(percu)}; wavefronts per CU: " + " ".join(f"{k}:{(ncu == k).sum()}" for k in sorted(set(ncu))))
 for k in sorted(set(ncu)):
     print(f"  CUs with {k} wavefronts: last wavefront ends at {lastcu[ncu == k].mean():6.2f} us (max {lastcu[ncu == k].max():6.2f})")
+
+# ---- the tail: the launch ends with its last wavefront.  Which wavefronts are last, and where did they lose time?
+order = np.argsort(-endt * okw)
+med = np.median(np.diff(st[okw][:, 0:16], axis=1), axis=0)
+print("latest wavefronts: end us | start us | block wave | xcc se cu simd slot | phase durations minus the median of all wavefronts (cycles), flags")
+short = ["loads", "sample", "bar1", "move", "bar2", "tags", "bound", "pass1", "chain", "resolve", "ids", "idrows", "obs", "bar3", "end"]
+for i in order[:24]:
+    d = np.diff(st[i, 0:16]) - med
+    big = " ".join(f"{short[k]}{int(d[k]):+d}" for k in np.argsort(-np.abs(d))[:5])
+    h = int(hw[i])
+    print(f"  {endt[i]:6.2f} | {(st[i, 16] - t0) / 100.0:5.2f} | {i // 2:5d} {i % 2} | {(h >> 32) & 15} {(h >> 13) & 7} {(h >> 8) & 15:2d} {(h >> 4) & 3} {h & 15:2d} | {big} | {int(st[i, 18]):x} {int(st[i, 20])}")
+print("end time by XCD (mean / max):", " ".join(f"{x}:{endt[okw & (((hw >> 32) & 15) == x)].mean():.1f}/{endt[okw & (((hw >> 32) & 15) == x)].max():.1f}" for x in range(8)))
