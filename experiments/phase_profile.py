@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 name = sys.argv[1] if len(sys.argv) > 1 else "prof"
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 T_STAMP = int(sys.argv[3]) if len(sys.argv) > 3 else 300  # (episodes are 500 ticks; the live-agent count falls along them)
+N_RUNNERS = int(sys.argv[4]) if len(sys.argv) > 4 else 100  # 5 taggers + this many runners per replica
 os.environ["WD_HSACO"] = os.path.join(ROOT, "build", "variants", f"{name}.hsaco")
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import time
@@ -26,7 +27,8 @@ from warp_drive_amd.managers.function_manager import HIPSampler
 from warp_drive_amd.rollout import RolloutEngine
 from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 
-w = EnvWrapper(env_obj=TagContinuous(**bench.BENCH_CFG), num_envs=E, env_backend="hip")
+w = EnvWrapper(env_obj=TagContinuous(**dict(bench.BENCH_CFG, num_runners=N_RUNNERS)), num_envs=E, env_backend="hip")
+WPB = (w.n_agents + 63) // 64  # wavefronts per block (one replica per block beyond 64 agents)
 w.reset_all_envs()
 sampler = HIPSampler(w.cuda_function_manager)
 sampler.init_random(seed=1)
@@ -34,7 +36,7 @@ create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, trainin
                                   push_data_batch_placeholders=False)
 engine = RolloutEngine(w, sampler, fused=True)
 SLOTS = 24
-n_waves = 2 * E
+n_waves = WPB * E
 buf = drv.mem_alloc(n_waves * SLOTS * 8)
 drv.memset(buf, 0, n_waves * SLOTS * 8)
 sym, nbytes = w.cuda_function_manager._module.get_global("tc_prof_g")
@@ -75,8 +77,8 @@ for k in range(1, 16):
 names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "search: bound", "search: pass 1 (list)",
          "search: chain (pass 2 / full)", "search: keys resolved", "search: ids, remember", "id rows + barrier + nearest ids flushed",
          "obs gathered+flushed", "barrier3", "rewards/end"]
-for wv, label in ((0, "wave 0 of each block (64 agents)"), (1, "wave 1 of each block (41 agents)")):
-    s = st[wv::2]
+for wv, label in ((0, "wave 0 of each block"), (WPB - 1, "the last wave of each block")):
+    s = st[wv::WPB]
     ok = (s[:, 6] > 0) & (s[:, 15] > 0)
     s = s[ok]
     print(f"--- {label}: {ok.sum()} waves; mean / p10 / p90 shader cycles per phase")
@@ -92,7 +94,7 @@ start, end = (s[:, 16] - t0) / 100.0, (s[:, 17] - t0) / 100.0
 pc = lambda a: " ".join(f"{np.percentile(a, q):6.2f}" for q in (0, 10, 50, 90, 99, 100))
 print("percentiles 0/10/50/90/99/100 (us): wave start", pc(start), "| wave end", pc(end), "| lifetime", pc(end - start))
 # absolute timeline of the phase boundaries (us since the first wave started), wave 0 only
-s0 = st[0::2]
+s0 = st[0::WPB]
 s0 = s0[(s0[:, 6] > 0) & (s0[:, 15] > 0)]
 ghz = ((s0[:, 15] - s0[:, 0]) / ((s0[:, 17] - s0[:, 16]) * 10.0)).mean()
 base = (s0[:, 16] - t0) / 100.0
@@ -105,7 +107,7 @@ for k in range(0, 16):
 hw = st[:, 21]
 okw = st[:, 15] > 0
 simd_key = ((hw >> 32) & 15) * (1 << 20) + ((hw >> 13) & 7) * (1 << 16) + ((hw >> 12) & 1) * (1 << 12) + ((hw >> 8) & 15) * 16 + ((hw >> 4) & 3)
-role = np.arange(len(st)) % 2   # 0 = wave 0 of its block (the searcher when <= 64 agents are in the game)
+role = np.arange(len(st)) % WPB   # 0 = wave 0 of its block (the searcher when <= 64 agents are in the game)
 endt = (st[:, 17] - t0) / 100.0
 import collections
 per = collections.defaultdict(list)
@@ -138,5 +140,5 @@ for i in order[:24]:
     d = np.diff(st[i, 0:16]) - med
     big = " ".join(f"{short[k]}{int(d[k]):+d}" for k in np.argsort(-np.abs(d))[:5])
     h = int(hw[i])
-    print(f"  {endt[i]:6.2f} | {(st[i, 16] - t0) / 100.0:5.2f} | {i // 2:5d} {i % 2} | {(h >> 32) & 15} {(h >> 13) & 7} {(h >> 8) & 15:2d} {(h >> 4) & 3} {h & 15:2d} | {big} | {int(st[i, 18]):x} {int(st[i, 20])}")
+    print(f"  {endt[i]:6.2f} | {(st[i, 16] - t0) / 100.0:5.2f} | {i // WPB:5d} {i % WPB} | {(h >> 32) & 15} {(h >> 13) & 7} {(h >> 8) & 15:2d} {(h >> 4) & 3} {h & 15:2d} | {big} | {int(st[i, 18]):x} {int(st[i, 20])}")
 print("end time by XCD (mean / max):", " ".join(f"{x}:{endt[okw & (((hw >> 32) & 15) == x)].mean():.1f}/{endt[okw & (((hw >> 32) & 15) == x)].max():.1f}" for x in range(8)))

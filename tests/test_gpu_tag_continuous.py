@@ -242,6 +242,8 @@ def test_bench_full_size_properties():
     (False, 3, 3, 130, 4, 3),      # more than 128 agents: three wavefronts per replica, 9-bit search keys
     (True, 2, 5, 60, 3, 4),        # full observations whose width is a multiple of four (16-byte stores)
     (False, 70, 3, 10, 3, 2),      # action table larger than its LDS copy (71 > 64 entries)
+    (False, 6, 8, 400, 6, 3),      # more than 256 agents: the two heads are sampled one after the other from ONE slab
+    (False, 20, 20, 1000, 10, 2),  # 1004 agents: sixteen wavefronts per replica, 10-bit search keys (`_N1024` entry)
 ])
 def test_fused_tick_kernel(full_obs, acc_levels, turn_levels, runners, K, E):
     """HipTagContinuousTick: sampling + step + in-kernel reset in ONE launch.  The actions it
@@ -562,10 +564,10 @@ def test_exact_and_sqrt_ties_at_the_cut(K):
         assert ids[0, 0, 0] == 1
 
 
-@pytest.mark.parametrize("K,n_runners", [(3, 10), (6, 10), (3, 180), (6, 180)])
+@pytest.mark.parametrize("K,n_runners", [(3, 10), (6, 10), (3, 180), (6, 180), (3, 600), (6, 600)])
 def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
     """The one-pass search orders candidates by squared distance with the low 7 bits dropped (buckets of
-    128 ulps; 9 bits = 512 ulps for replicas of more than 128 agents) and must rebuild the reference's
+    128 ulps; 9 bits = 512 ulps for replicas of more than 128 agents, 10 bits = 1024 ulps beyond 512) and must rebuild the reference's
     order exactly wherever that is too coarse.  One replica per case: agent 0's K-th and (K+1)-th
     candidates sit `delta` ulps of squared distance apart -- inside one bucket, across a bucket boundary,
     just inside / outside the 383-apart (1535-apart) rule -- with either id the closer one; with `triple` a
@@ -580,6 +582,8 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
     deltas = [0, 1, 2, 3, 60, 127, 128, 129, 200, 255, 256, 257, 382, 383, 384, 500, 2000]
     if n_runners > 126:  # the bucket boundaries of the 9-bit keys
         deltas += [511, 512, 513, 1023, 1024, 1025, 1534, 1535, 1536, 3000]
+    if n_runners > 510:  # ... and of the 10-bit keys (replicas of 513 .. 1024 agents: buckets of 1024 ulps, 3071-apart rule)
+        deltas += [2047, 2048, 2049, 3070, 3071, 3072, 4095, 4096, 4097, 6000]
     cases = [(d, swap, triple) for d in deltas for swap in (0, 1) for triple in (0, 1)]
     E = len(cases)
     w = _mk(cfg, E)
@@ -632,16 +636,24 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
 
 
 @pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (300, 10, False), (500, 10, False),
-                                                  (525, 5, False), (1020, 3, False)])
+                                                  (525, 5, False), (1020, 3, False), (1000, 10, False), (700, 16, False),
+                                                  (600, 20, False)])
 def test_many_agents_paths(n_runners, K, full_obs):
-    """replicas of more than 128 agents: up to 512 agents with partial observations take the fast path
-    (blocks of up to eight wavefronts, 9 id bits in the search keys); beyond that, and for full
-    observations, the generic entry points (tc_generic_impl: K-pass selection, one block of up to 1024
-    threads per replica)"""
+    """replicas of more than 128 agents: with partial observations up to 512 agents take the fast path with 9 id bits
+    in the search keys (blocks of up to eight wavefronts), 513 .. 1024 agents the `_N1024` entries (10 id bits, blocks
+    of up to sixteen wavefronts, K <= 16); full observations and K > 16 beyond 512 agents take the generic entry
+    points (tc_generic_impl: K-pass selection, one block of up to 1024 threads per replica)"""
     cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=30.0, episode_length=6, seed=13,
                max_acceleration=0.2, min_acceleration=-0.2, num_acceleration_levels=5, num_turn_levels=5,
                use_full_observation=full_obs, num_other_agents_observed=K, tagging_distance=0.2,
                runner_exits_game_after_tagged=True)
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+
+    name = TagContinuous(**cfg).resolve_step_function_name("HipTagContinuousStep")
+    N = 4 + n_runners
+    want = ("HipTagContinuousStep" if (full_obs or (N > 512 and K > 16)) else
+            f"HipTagContinuousStep_K{min(k for k in (4, 8, 10, 12, 16) if k >= K)}_N1024" if N > 512 else None)
+    assert want is None or name == want, (name, want)
     _run_lockstep(cfg, E=3, ticks=8, seed=n_runners)
 
 
@@ -671,15 +683,16 @@ def test_random_configurations(case):
 
 
 def test_rollout_falls_back_when_the_tick_does_not_fit_lds():
-    """~1000 agents x two 21-way heads: the probability slabs exceed a workgroup's LDS, so the rollout
-    engine must use the separate launches (and still run)"""
+    """~1000 agents x 41-way heads: even ONE head's probability slab (165 KB) exceeds a workgroup's LDS, so the
+    rollout engine must use the separate launches (and still run).  (With 21-way heads the tick does fit since
+    round 4: the heads are sampled one after the other from one slab, test_fused_tick_kernel.)"""
     import torch
     from tests.hip_harness import pull
     from warp_drive_amd.managers.function_manager import HIPSampler
     from warp_drive_amd.rollout import RolloutEngine
 
     cfg = dict(num_taggers=4, num_runners=1000, grid_length=40.0, episode_length=5, seed=3,
-               num_acceleration_levels=20, num_turn_levels=20, use_full_observation=False,
+               num_acceleration_levels=40, num_turn_levels=40, use_full_observation=False,
                num_other_agents_observed=3, tagging_distance=0.05)
     w = _mk(cfg, 2)
     assert not w.env.can_fuse_tick()

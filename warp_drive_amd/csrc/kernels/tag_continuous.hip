@@ -206,6 +206,20 @@ struct TcIn {
   int cleared;              // obs_rows_cleared[agent] (fast path)
 };
 
+// this wavefront's 64 rows of one head's probability tensor -> LDS (asynchronous: wd_slab_fetch)
+__device__ __forceinline__ void tc_fetch_slab(float *slab, const float *probs, const TcArgs &a, int env0, int epb, int N,
+                                              int n_actions, int tid) {
+  const int rows_here = min(epb, a.E - env0) * N;
+  const int r0 = (tid >> 6) * 64, lane = tid & 63;
+  const int wrows = max(0, min(64, rows_here - r0));
+  wd_slab_fetch(slab + (size_t)r0 * n_actions, probs + ((long)env0 * N + r0) * n_actions, wrows * n_actions, lane);
+}
+
+// Replicas of more than 256 agents sample the two heads one after the other from ONE slab (the second head's rows
+// are fetched into the same LDS after the first head was sampled: wave-private rows, no block barrier): both slabs
+// of a 1005-agent replica with 21-way heads are 169 KB, and at ~510 agents half the LDS means two blocks per CU.
+__device__ __forceinline__ bool tc_one_slab(int N) { return N > 256; }
+
 template <bool FUSED>
 __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const TcFuse &fz, int env0, int epb,
                                                int N, int n_acc, int n_turn, int tid, float *slab_acc,
@@ -245,13 +259,9 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
     if (FUSED) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
   }
   if (FUSED) {
-    // this wavefront's rows of both probability slabs -> LDS
-    const int rows_here = min(epb, a.E - env0) * N;
-    const int r0 = (tid >> 6) * 64, lane = tid & 63;
-    const int wrows = max(0, min(64, rows_here - r0));
-    wd_slab_fetch(slab_acc + (size_t)r0 * n_acc, fz.probs_acc + ((long)env0 * N + r0) * n_acc, wrows * n_acc, lane);
-    wd_slab_fetch(slab_turn + (size_t)r0 * n_turn, fz.probs_turn + ((long)env0 * N + r0) * n_turn, wrows * n_turn,
-                  lane);
+    // this wavefront's rows of both probability slabs -> LDS (the second one later when they share the LDS)
+    tc_fetch_slab(slab_acc, fz.probs_acc, a, env0, epb, N, n_acc, tid);
+    if (!tc_one_slab(N)) tc_fetch_slab(slab_turn, fz.probs_turn, a, env0, epb, N, n_turn, tid);
   }
 }
 
@@ -301,9 +311,9 @@ __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs 
 
 // ---- fused tick: sample both action heads for this thread's agent (replaces two sample_actions
 // launches, random.cu:51-85): inverse CDF on a running float32 sum, one Philox call for both heads.
-__device__ __forceinline__ int2 tc_sample_heads(const TcFuse &fz, const TcIn &in, bool active, int gi, int li,
-                                                const float *slab_acc, const float *slab_turn, int n_acc,
-                                                int n_turn) {
+__device__ __forceinline__ int2 tc_sample_heads(const TcArgs &a, const TcFuse &fz, const TcIn &in, bool active, int gi,
+                                                int li, const float *slab_acc, float *slab_turn, int n_acc,
+                                                int n_turn, int env0, int epb) {
   int2 sampled = make_int2(0, 0);
   wd_u4 rnd = wd_u4{0u, 0u, 0u, 0u};
   if (active) {
@@ -315,8 +325,15 @@ __device__ __forceinline__ int2 tc_sample_heads(const TcFuse &fz, const TcIn &in
   // reads were all fetched by its own wavefront
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  if (active) sampled.x = wd_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
+  if (tc_one_slab(a.N)) {  // block-uniform: the second head's rows replace the first head's (slab_turn == slab_acc)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wavefront's reads of its rows are complete
+    __builtin_amdgcn_wave_barrier();
+    tc_fetch_slab(slab_turn, fz.probs_turn, a, env0, epb, a.N, n_turn, threadIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
   if (active) {
-    sampled.x = wd_slab_sample(slab_acc + (size_t)li * n_acc, n_acc, wd_u01_open_closed(rnd.x));
     sampled.y = wd_slab_sample(slab_turn + (size_t)li * n_turn, n_turn, wd_u01_open_closed(rnd.y));
     ((int2 *)fz.actions_out)[gi] = sampled;
   }
@@ -863,7 +880,7 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
 
 // nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
 // `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
-// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512 (buckets of 2^IDB ulps of d2;
+// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512, 10 for up to 1024 (buckets of 2^IDB ulps of d2;
 // the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
 // at least 2^(IDB-1) - 1 ulps of the float32 distance)
 // S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
@@ -1319,10 +1336,13 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // average over a 500-tick episode (105 at the start, ~27 at the end).  Packing preserves the id
   // order, so ties break exactly as before; ids are translated back through `cid`.
   const bool compact = (epb == 1);
+  const size_t slab_turn_bytes = tc_align16((size_t)4 * epb * N * n_turn);
+  const bool one_slab = tc_one_slab(N);
   const TcFastLds l = tc_carve_fast(smem, epb, N, K, n_waves,
-                                    FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0, compact);
+                                    !FUSED ? 0 : one_slab ? max(slab_acc_bytes, slab_turn_bytes) : slab_acc_bytes + slab_turn_bytes,
+                                    compact);
   const TcTables &tb = l.tb;
-  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
+  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + (one_slab ? 0 : slab_acc_bytes));
   float *const stage = l.stage + (size_t)wave * l.stage_dwords;
   const int el = tid / N, ag = tid - el * N;
   const float invK = 1.0f / (float)K, invN = 1.0f / (float)N;
@@ -1359,7 +1379,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   if (compact && lane == 0) tb.live_cnt[wave] = __popcll(live_mask);
   if (FUSED) {
     if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
-    sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
+    sampled = tc_sample_heads(a, fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn, env0, epb);
   }
   WD_TC_PROBE(2);
   __syncthreads();  // tables are published; every wavefront is done with the slabs
@@ -1690,10 +1710,12 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int epb = max(1, T_ / N);
   const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
+  const size_t slab_turn_bytes = tc_align16((size_t)4 * epb * N * n_turn);
+  const bool one_slab = tc_one_slab(N);
   const TcGenLds l = tc_carve_generic(smem, epb, N, K,
-                                      FUSED ? slab_acc_bytes + tc_align16((size_t)4 * epb * N * n_turn) : 0);
+                                      !FUSED ? 0 : one_slab ? max(slab_acc_bytes, slab_turn_bytes) : slab_acc_bytes + slab_turn_bytes);
   const TcTables &tb = l.tb;
-  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + slab_acc_bytes);
+  float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + (one_slab ? 0 : slab_acc_bytes));
   const int el = tid / N, ag = tid - el * N;
 
   int env0 = a.env_begin + blockIdx.x * epb;
@@ -1711,7 +1733,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
     int2 sampled = in.sampled;
     if (FUSED) {
       if (active && ag == 0) a.done[env] = 0;
-      sampled = tc_sample_heads(fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn);
+      sampled = tc_sample_heads(a, fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn, env0, epb);
     }
     __syncthreads();
 
@@ -1938,6 +1960,26 @@ __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
     else if (a.K == KM) tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
     else tc_fast_impl<KM, true, false, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }
+// replicas of 513 .. 1024 agents: blocks of up to sixteen wavefronts (1024 threads: the reference's default geometry
+// serves up to 1024 agents per block, managers/function_manager.py:64-67), 10 id bits in the search keys (buckets of
+// 1024 ulps of d2: the exactness argument of tc_resolve_keys holds for any bucket width)
+#define WD_TC_SPECIALISE_BIG(KM)                                                                    \
+  __global__ void __launch_bounds__(1024, 4) HipTagContinuousStep_K##KM##_N1024(WD_TC_PARAMS) {       \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    tc_fast_impl<KM, false, false, 10>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+  }                                                                                            \
+  __global__ void __launch_bounds__(1024, 4) HipTagContinuousTick_K##KM##_N1024(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    WD_TC_FUSE_PACK();                                                                         \
+    tc_fast_impl<KM, true, false, 10>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+  }
+WD_TC_SPECIALISE_BIG(4)
+WD_TC_SPECIALISE_BIG(8)
+WD_TC_SPECIALISE_BIG(10)
+WD_TC_SPECIALISE_BIG(12)
+WD_TC_SPECIALISE_BIG(16)
 WD_TC_SPECIALISE(2, 4)
 WD_TC_SPECIALISE(4, 4)
 WD_TC_SPECIALISE(6, 4)

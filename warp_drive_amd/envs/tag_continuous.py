@@ -296,21 +296,25 @@ class TagContinuous(CUDAEnvironmentContext):
         "num_acceleration_actions", "num_turn_actions", "obs_rows_cleared",
     ]  # + kEnvBegin appended by step_launch / tick_launch
 
-    FAST_PATH_MAX_AGENTS = 512   # tc_fast_impl: blocks of up to 512 threads (9 id bits in the search keys beyond 128 agents)
+    FAST_PATH_MAX_AGENTS = 1024  # tc_fast_impl: 7 id bits in the search keys up to 128 agents, 9 up to 512 (blocks of up to
+                                 # 512 threads), 10 up to 1024 (the `_N1024` entries: blocks of 1024 threads)
+    _K_SPECIALISATIONS_N1024 = (4, 8, 10, 12, 16)
     STAGE_TARGET_BYTES = 5400    # WD_TC_STAGE_TARGET in tag_continuous.hip
 
     def _fast_path(self):
+        ks = _K_SPECIALISATIONS if self.num_agents <= 512 else self._K_SPECIALISATIONS_N1024
         return (not self.use_full_observation and self.num_agents <= self.FAST_PATH_MAX_AGENTS
-                and 1 <= self.num_other_agents_observed <= _K_SPECIALISATIONS[-1])
+                and 1 <= self.num_other_agents_observed <= ks[-1])
 
     def resolve_step_function_name(self, default_name):
         """The register-resident top-K specialisation that covers K (N <= 512, partial obs), else the
         generic kernel."""
         if not self._fast_path():
             return default_name
-        for k in _K_SPECIALISATIONS:
+        big = self.num_agents > 512
+        for k in (self._K_SPECIALISATIONS_N1024 if big else _K_SPECIALISATIONS):
             if k >= self.num_other_agents_observed:
-                return f"{default_name}_K{k}"
+                return f"{default_name}_K{k}" + ("_N1024" if big else "")
         return default_name
 
     def lds_bytes(self, epb, fused=False, threads=None):
@@ -334,8 +338,10 @@ class TagContinuous(CUDAEnvironmentContext):
             area = align16(area + 2 * A * K) + 4 * stage_dwords * n_waves  # 16-bit neighbour ids, staging
         else:
             area = 32 * A + align16(4 * A * max(K, 1)) + 4 * 4 * A
-        if fused:  # the work area doubles as the two probability slabs (global_load_lds targets)
-            area = max(area, align16(4 * A * len(self.acceleration_actions)) + align16(4 * A * len(self.turn_actions)))
+        if fused:  # the work area doubles as the two probability slabs (global_load_lds targets); replicas of more
+            # than 256 agents sample the heads one after the other from ONE slab (tc_one_slab in the kernel file)
+            slabs = (align16(4 * A * len(self.acceleration_actions)), align16(4 * A * len(self.turn_actions)))
+            area = max(area, max(slabs) if N > 256 else sum(slabs))
         return align16(area) + 4 * N + 4 * (2 * 64 + 32) + 4 * 4 * epb + 16   # + tagger list, action tables, per-wavefront counts, per-replica scalars
 
     def _geometry(self):
