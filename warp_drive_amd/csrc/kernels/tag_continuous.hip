@@ -878,6 +878,56 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
   for (int k = 0; k < L; ++k) S[k] = c[k];
 }
 
+// ---- exact resolution for ONE searcher by the WHOLE wavefront (replicas of more than 128 agents; the K-pass scan
+// above took ~1.5 ms for a 1005-agent replica -- ten times the rest of the tick -- and a launch of 2000 replicas hit it
+// in ~11 wavefronts, so the launch waited for it on every tick).  The chain already located the cut: the answer lies
+// in the key buckets <= `zone_hi` (= the bucket of the K-th other agent + 1).  Lane l looks at candidates l, l + 64,
+// ...; the candidates inside the zone are packed (ballot + mbcnt: ascending index order) into a list in the
+// wavefront's staging buffer; each lane builds the exact (float32 distance, index) key of one listed candidate and
+// counts the smaller keys (LDS broadcast reads); rank r < K writes its index to out[r].  ~25 instructions per 64
+// candidates + ~4 per listed candidate.  Returns the number of candidates in the zone (> 64: not resolved, the
+// caller falls back to the scan -- a pile of agents on one spot).
+__device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, float sx, float sy, int self, unsigned zone_hi,
+                                               int idb, int K, unsigned char *scratch, int lane) {
+  unsigned short *const zl = (unsigned short *)scratch;                  // [64] candidate indices inside the zone
+  unsigned long long *const keys = (unsigned long long *)(scratch + 128);  // [64] exact keys
+  unsigned short *const out = (unsigned short *)(scratch + 128 + 512);     // [K] the K nearest in the reference's order
+  int cnt = 0;  // wave-uniform
+  for (int j0 = 0; j0 < n_cand; j0 += 64) {
+    const int j = j0 + lane;
+    bool in = false;
+    if (j < n_cand) {
+      const float2 pj = cxy[j];
+      const float dx = sx - pj.x, dy = sy - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      in = (j != self) && ((__float_as_uint(d2) >> idb) <= zone_hi);
+    }
+    const unsigned long long m = __ballot(in);
+    const int at = cnt + __popcll(m & ((1ull << lane) - 1ull));
+    if (in && at < 64) zl[at] = (unsigned short)j;
+    cnt += __popcll(m);
+  }
+  if (cnt > 64) return cnt;
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long mine = ~0ull;
+  if (lane < cnt) {
+    const int j = zl[lane];
+    const float2 pj = cxy[j];
+    const float dx = sx - pj.x, dy = sy - pj.y;
+    mine = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)j;
+    keys[lane] = mine;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  int r = 0;
+  for (int u = 0; u < cnt; ++u) r += (keys[u] < mine) ? 1 : 0;  // (wave-uniform address: a broadcast read)
+  if (lane < cnt && r < K) out[r] = (unsigned short)(mine & 0xffffu);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
+}
+
 // nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
 // `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
 // IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512, 10 for up to 1024 (buckets of 2^IDB ulps of d2;
@@ -1486,31 +1536,82 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       tc_merge_sorted<L>(S, P);
     }
   }
+  bool exact = true;
+  unsigned zone_hi = 0u;
   if (searcher) {
     // a lane with three candidates inside 256 ulps at the cut (~1e-7 per agent) repeats the search with the
-    // two-pass one
+    // two-pass one (up to 128 candidates) / has the whole wavefront resolve it (more)
     unsigned o[L - 1];
     __builtin_amdgcn_s_setprio(1);
-    bool exact = tc_resolve_keys<KMAX, IDB, L>(sxy, ag, K, S, o, nid, rank, in_order);
+    exact = tc_resolve_keys<KMAX, IDB, L>(sxy, ag, K, S, o, nid, rank, in_order);
     WD_TC_PROBE(10);
-    if (!exact) {
+    {  // the last key bucket the answer can come from: the K-th other agent's + 1
+      unsigned oKth = o[KMAX - 1];
+#pragma unroll
+      for (int k = 0; k < KMAX - 1; ++k) oKth = (k == K - 1) ? o[k] : oKth;
+      zone_hi = (oKth >> IDB) + 1u;
+    }
+    if (!exact && (IDB == 7 || n_cand <= 128)) {
       WD_TC_PROBE_VAL(20, 1);
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid2[k] = -1; rank2[k] = k; }
-      if (IDB == 7 || n_cand <= 128) tc_knn_registers<KMAX>(sxy, ag, n_cand, K, nid2, rank2);
-      else tc_knn_scan<KMAX>(sxy, ag, n_cand, K, nid2);  // (entries in the reference's order: rank2[k] = k)
+      tc_knn_registers<KMAX>(sxy, ag, n_cand, K, nid2, rank2);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = rank2[k]; }
       nid[KMAX] = -1;
       rank[KMAX] = KMAX;
       in_order = false;
+      exact = true;
     }
-    if (compact) {  // packed indices -> agent ids (cid[0] = -1 stands for "none")
-      row_agent = l.cid[1 + ag];
+  }
+  if constexpr (IDB != 7) {
+    // more than 128 candidates: the lanes that need the exact resolution get it from the whole wavefront, one
+    // after the other (tc_zone_resolve)
+    unsigned long long need = __ballot(searcher && !exact);  // wave-uniform
+    if (need != 0ull) {
+      WD_TC_PROBE_VAL(20, 1);
+      unsigned long long unresolved = 0ull;
+      const float mx = searcher ? sxy[ag].x : 0.0f, my = searcher ? sxy[ag].y : 0.0f;
+      while (need != 0ull) {
+        const int fl = __ffsll((long long)need) - 1;
+        need &= need - 1ull;
+        const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), fl));
+        const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my), fl));
+        const unsigned zh = (unsigned)__builtin_amdgcn_readlane((int)zone_hi, fl);
+        const int self = __builtin_amdgcn_readlane(ag, fl);
+        const int cnt = tc_zone_resolve(sxy, n_cand, sx, sy, self, zh, IDB, K, (unsigned char *)stage, lane);
+        if (cnt > 64) {
+          unresolved |= 1ull << fl;
+        } else {
+          const unsigned short *const out = (const unsigned short *)((const unsigned char *)stage + 128 + 512);
 #pragma unroll
-      for (int k = 0; k <= KMAX; ++k) nid[k] = l.cid[1 + nid[k]];
+          for (int k = 0; k < KMAX; ++k) {
+            const int v = (k < K) ? (int)out[k] : -1;
+            if (lane == fl) { nid[k] = v; rank[k] = k; }
+          }
+          if (lane == fl) { nid[KMAX] = -1; rank[KMAX] = KMAX; in_order = false; }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if ((unresolved >> lane) & 1ull) {  // more than 64 candidates inside the zone: the K-pass scan, this lane alone
+        int nid2[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) nid2[k] = -1;
+        tc_knn_scan<KMAX>(sxy, ag, n_cand, K, nid2);  // (entries in the reference's order)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = k; }
+        nid[KMAX] = -1;
+        rank[KMAX] = KMAX;
+        in_order = false;
+      }
     }
+  }
+  if (searcher && compact) {  // packed indices -> agent ids (cid[0] = -1 stands for "none")
+    row_agent = l.cid[1 + ag];
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) nid[k] = l.cid[1 + nid[k]];
   }
   __builtin_amdgcn_s_setprio(0);
   WD_TC_PROBE(11);
