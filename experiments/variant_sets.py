@@ -292,3 +292,18 @@ SETS["hybrid_thr"] = {
     "thr11": [(TC, _THR, "  if (n_live_rows * 16 <= wrows * 11) {")],
     "thr0_dense_only": [(TC, _THR, "  if (n_live_rows < 0) {")],
 }
+
+
+# ---- round 4: which of the TagGridWorld rollout changes costs time? (same-box A/B: `variants.py bench gw 2 --workload
+# tag_gridworld --ticks-per-launch 200 --steps 100 --warmup 10`)
+GW = "tag_gridworld.hip"
+_GW_NOCACHE = [(GW, "  uint32_t *const s_cache = (uint32_t *)(s_obs + (size_t)A * F);   // [epb][reset_cache_dwords]",
+                "  uint32_t *const s_cache = (uint32_t *)(s_obs + (size_t)A * F);\n  reset_cache_dwords = 0;")]
+_GW_PHILOX_EVERY_TICK = [(GW, "        const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)idx, epoch0 + (uint32_t)k, (uint32_t)fz.stream_tag, k0, k1,\n                                                        blk, blk_quad));",
+                          "        blk_quad = 0xffffffffu;\n        const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)idx, epoch0 + (uint32_t)k, (uint32_t)fz.stream_tag, k0, k1,\n                                                        blk, blk_quad));")]
+_GW_ROW_REBUILD = [(GW, "        if (use_full_observation) {\n          // Only 2 N + 1 of a row's 4 N + 1 values change from tick to tick",
+                    "        if (false) {\n          // Only 2 N + 1 of a row's 4 N + 1 values change from tick to tick"),
+                   (GW, "        if (!use_full_observation) {\n          s_fx[li] = fx;\n          s_fy[li] = fy;\n        }",
+                    "        s_fx[li] = fx;\n        s_fy[li] = fy;")]
+SETS["gw"] = {"base": [], "nocache": _GW_NOCACHE, "philox_every_tick": _GW_PHILOX_EVERY_TICK, "row_rebuild": _GW_ROW_REBUILD,
+              "all_old": _GW_NOCACHE + _GW_PHILOX_EVERY_TICK + _GW_ROW_REBUILD}

@@ -118,3 +118,15 @@ def fused_tick_uniforms(n_rows, epochs, seed_lo, seed_hi, stream_tag):
     x, y, _, _ = philox4x32_10(rows, np.asarray(epochs, dtype=np.uint32), np.uint32(stream_tag), np.uint32(3),
                                seed_lo, seed_hi)
     return u01_open_closed(x), u01_open_closed(y)
+
+
+def single_head_tick_uniform(n_rows, epochs, seed_lo, seed_hi, stream_tag):
+    """The uniform the fused tick of a SINGLE-head env (TagGridWorld, Cartpole) draws for every agent row:
+    word (epoch & 3) of the Philox block with counter (row, epoch >> 2, stream_tag, 4), key (seed_lo, seed_hi)
+    (csrc/kernels/wd_common.h::wd_tick_draw: a T-tick launch needs one Philox call per four ticks)."""
+    rows = np.arange(n_rows, dtype=np.uint32)
+    ep = np.broadcast_to(np.asarray(epochs, dtype=np.uint32), rows.shape)
+    words = philox4x32_10(rows, ep >> np.uint32(2), np.uint32(stream_tag), np.uint32(4), seed_lo, seed_hi)
+    sel = (ep & np.uint32(3)).astype(np.int64)
+    bits = np.choose(sel, [np.asarray(w, dtype=np.uint32) for w in words])
+    return u01_open_closed(bits.astype(np.uint32))

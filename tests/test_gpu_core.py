@@ -384,7 +384,7 @@ def test_cartpole_fused_tick(ticks):
     The CPU side replays the kernel's Philox draws tick by tick through the oracle."""
     import torch
     from oracle.cartpole_np import CartPoleOracle
-    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from oracle.core_np import sample_actions_counting, single_head_tick_uniform
     from tests.hip_harness import OBS, REW, make_wrapper, pull, require_gpu
     from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
     from warp_drive_amd.managers import hip_driver as drv
@@ -414,7 +414,7 @@ def test_cartpole_fused_tick(ticks):
         engine.run(1)
         torch.cuda.synchronize()
         for k in range(ticks):
-            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            u = single_head_tick_uniform(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
             a = sample_actions_counting(probs_host, u.reshape(E, 1))
             orc.step(a.reshape(E, 1, 1))
             last = k == ticks - 1
@@ -438,7 +438,7 @@ def test_cartpole_rollout_records_every_tick():
     (trainer_base.py:392-426 records exactly these per tick.)"""
     import torch
     from oracle.cartpole_np import CartPoleOracle
-    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from oracle.core_np import sample_actions_counting, single_head_tick_uniform
     from tests.hip_harness import OBS, make_wrapper, pull, require_gpu
     from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
     from warp_drive_amd.managers import hip_driver as drv
@@ -472,7 +472,7 @@ def test_cartpole_rollout_records_every_tick():
         b = {k: v.cpu().numpy() for k, v in batch.items()}
         for k in range(ticks):
             np.testing.assert_array_equal(b["obs"][k, :, 0], orc.obs, err_msg=f"obs row {k} of launch {launch}")
-            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            u = single_head_tick_uniform(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
             a = sample_actions_counting(probs_host, u.reshape(E, 1))
             orc.step(a.reshape(E, 1, 1))
             np.testing.assert_array_equal(b["actions"][k, :, 0, 0], a[:, 0])
@@ -497,7 +497,7 @@ def test_cartpole_rollout_with_the_policy_inside_the_kernel(hidden):
     action.  And T single-tick launches of the same kernel record the same rows as one T-tick launch."""
     import torch
     from oracle.cartpole_np import CartPoleOracle, policy_probabilities
-    from oracle.core_np import fused_tick_uniforms
+    from oracle.core_np import single_head_tick_uniform
     from tests.hip_harness import make_wrapper, pull, require_gpu
     from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
     from warp_drive_amd.managers import hip_driver as drv
@@ -549,7 +549,7 @@ def test_cartpole_rollout_with_the_policy_inside_the_kernel(hidden):
                 np.testing.assert_array_equal(batch1[key][0].cpu().numpy(), b[key][k], err_msg=f"{key} row {k}")
             np.testing.assert_array_equal(b["obs"][k, :, 0], orc.obs, err_msg=f"obs row {k} of launch {launch}")
             p = policy_probabilities(packed.cpu().numpy(), hidden, orc.obs)
-            u, _ = fused_tick_uniforms(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            u = single_head_tick_uniform(E, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
             want = (p[:, 0] < u).astype(np.int32)  # number of running sums below u, clamped to the last action
             got = b["actions"][k, :, 0, 0]
             bad = got != want

@@ -128,7 +128,7 @@ def test_gridworld_fused_tick(full_obs, E):
     through the oracle; finished replicas must already be reset when the launch returns while
     `_done_` still reports them."""
     import torch
-    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from oracle.core_np import sample_actions_counting, single_head_tick_uniform
     from tests.hip_harness import OBS, REW, pull, ulp_diff
     from warp_drive_amd.managers import hip_driver as drv
     from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
@@ -158,7 +158,7 @@ def test_gridworld_fused_tick(full_obs, E):
         engine.run(1)
         torch.cuda.synchronize()
         a = pull(w, "sampled_actions")[..., 0]
-        u, _ = fused_tick_uniforms(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
+        u = single_head_tick_uniform(E * N, rng_words[4:], rng_words[0], rng_words[1], _stream_tag("tick"))
         np.testing.assert_array_equal(a, sample_actions_counting(probs_host, u.reshape(E, N)), err_msg=f"t={t}")
         orc.step(a)
         np.testing.assert_array_equal(pull(w, "_done_"), orc.done, err_msg=f"done t={t}")   # still set
@@ -189,7 +189,7 @@ def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
     observations exact, rewards <= 1 ulp as everywhere for this env); finished replicas restart inside the launch;
     the per-tick arrays hold the state after the last tick."""
     import torch
-    from oracle.core_np import fused_tick_uniforms, sample_actions_counting
+    from oracle.core_np import sample_actions_counting, single_head_tick_uniform
     from tests.hip_harness import OBS, pull, ulp_diff
     from warp_drive_amd.managers import hip_driver as drv
     from warp_drive_amd.managers.function_manager import HIPSampler, _stream_tag
@@ -229,7 +229,7 @@ def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
         b = {k: v.cpu().numpy() for k, v in batch.items()}
         for k in range(ticks):
             np.testing.assert_array_equal(b["obs"][k], orc.obs.astype(np.float32), err_msg=f"obs row {k} of launch {launch}")
-            u, _ = fused_tick_uniforms(E * N, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
+            u = single_head_tick_uniform(E * N, rng_words[4:] + np.uint32(k), rng_words[0], rng_words[1], _stream_tag("tick"))
             a = sample_actions_counting(probs_host, u.reshape(E, N))
             np.testing.assert_array_equal(b["actions"][k, :, :, 0], a, err_msg=f"actions row {k}")
             orc.step(a)

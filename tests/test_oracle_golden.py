@@ -229,6 +229,24 @@ def test_philox_known_answers():
     assert u.dtype == np.float32 and u[0] == np.float32(2.0 ** -24) and u[1] == 1.0 and u[2] == np.float32(0.5) + np.float32(2.0 ** -24)
 
 
+def test_single_head_tick_draw_is_word_epoch_mod_4_of_the_block():
+    """single-head fused ticks draw word (epoch & 3) of the Philox block (row, epoch >> 2, tag, 4): four consecutive
+    epochs of a row share one block (csrc/kernels/wd_common.h::wd_tick_draw)"""
+    from oracle.core_np import philox4x32_10, single_head_tick_uniform, u01_open_closed
+
+    rows, tag, k0, k1 = 37, 0x1234567, 0xDEADBEEF, 0x42
+    for e0 in (0, 5, 4094, 0xFFFFFFFC):
+        for d in range(4):
+            ep = np.full(rows, (e0 & ~3) + d, dtype=np.uint32)
+            words = philox4x32_10(np.arange(rows, dtype=np.uint32), ep >> np.uint32(2), np.uint32(tag), np.uint32(4), k0, k1)
+            np.testing.assert_array_equal(single_head_tick_uniform(rows, ep, k0, k1, tag), u01_open_closed(words[d]))
+    mixed = np.arange(rows, dtype=np.uint32) * 3 + 1   # different epochs per row
+    u = single_head_tick_uniform(rows, mixed, k0, k1, tag)
+    for r in (0, 7, 36):
+        w = philox4x32_10(np.uint32(r), mixed[r] >> np.uint32(2), np.uint32(tag), np.uint32(4), k0, k1)
+        assert u[r] == u01_open_closed(w[int(mixed[r]) & 3])
+
+
 CP_TOL = 1e-5  # absolute, on positions / velocities / angles of O(1)
 
 

@@ -105,8 +105,8 @@ __device__ __forceinline__ void cp_policy_cum(const float *w, const float4 &s, i
 }
 
 struct CpResetEntry {  // same layout as wd_reset_entry in wd_core.hip
-  uint32_t *data;
-  const uint32_t *ref;
+  wd_global_u32 *data;
+  const wd_global_u32 *ref;
   int row_elems;
   int pad_;
 };
@@ -150,10 +150,30 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
     int t = env_timestep_arr[env];
     float4 s = state_arr[env];
     const uint32_t epoch0 = rng_state[WD_RNG_HEADER + env];
+    wd_u4 blk = wd_u4{0u, 0u, 0u, 0u};   // the Philox block of four consecutive ticks (wd_tick_draw)
+    uint32_t blk_quad = 0xffffffffu;
     const float *row = probs + (long)env * n_actions;
     // The running float32 sums of the (fixed) probabilities, once per launch and in registers: a load
     // inside the tick loop would wait for every store issued before it (the memory counters return in
     // order) -- 2.9 us per tick at 100 000 replicas instead of 0.5.
+    // The rows a finished replica is restored from, preloaded ONCE (the usual registration: `state` and the
+    // observation, four floats each).  A random policy ends a Cartpole episode every ~20 ticks, so some lane of a
+    // wavefront finishes on nearly every tick; the restore used to LOAD the registered rows inside the tick loop
+    // (and reload the state): 12 loads per tick and wavefront, each waiting for every store issued before it (the
+    // memory counters return in order) -- 70 % of the wavefronts' cycles were waits (profiles/r04_pmc_mix_cartpole_T50.txt).
+    CpResetEntry ent0 = CpResetEntry{nullptr, nullptr, 0, 0}, ent1 = ent0;
+    uint4 row0 = make_uint4(0u, 0u, 0u, 0u), row1 = row0;
+    bool cached = (n_reset_arrays >= 1) && (n_reset_arrays <= 2);
+    if (cached) {
+      ent0 = table[0];
+      ent1 = (n_reset_arrays == 2) ? table[1] : table[0];
+      cached = (ent0.row_elems == 4) && (ent1.row_elems == 4) &&
+               ((size_t)ent0.data == (size_t)state_arr || (size_t)ent1.data == (size_t)state_arr);
+      if (cached) {
+        row0 = ((const uint4 __attribute__((address_space(1))) *)ent0.ref)[env];
+        row1 = ((const uint4 __attribute__((address_space(1))) *)ent1.ref)[env];
+      }
+    }
     float cumv[CP_MAX_REG_ACTIONS];
     if (H == 0) {
       float cum = 0.0f;
@@ -163,10 +183,16 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
         cumv[i] = cum;
       }
     }
+    // Every value loaded above is consumed HERE, before the tick loop: the wait for a load whose first use is inside
+    // the loop is placed inside the loop, executed on every tick, and also waits for every store of the previous tick.
+    asm volatile("" : "+v"(t), "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w));
+    asm volatile("" : "+v"(row0.x), "+v"(row0.y), "+v"(row0.z), "+v"(row0.w), "+v"(row1.x), "+v"(row1.y), "+v"(row1.z), "+v"(row1.w));
+#pragma unroll
+    for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) asm volatile("" : "+v"(cumv[i]));
     for (int k = 0; k < ticks; ++k) {
       // ---- sample (random.cu:51-85): inverse CDF on a running float32 sum
-      const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, 3u}, k0, k1);
-      const float u = wd_u01_open_closed(rnd.x);
+      const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, k0, k1,
+                                                      blk, blk_quad));
       if (H > 0) cp_policy_cum<(H > 0 ? H : 4)>(cp_weights, s, n_actions, cumv);  // live policy: THIS tick's observation
       int cnt = 0;
       if (n_actions <= CP_MAX_REG_ACTIONS) {
@@ -182,34 +208,47 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
       const int a = min(cnt, n_actions - 1);
       // ---- step
       const long brow = (long)k * n_envs + env;
-      if (obs_batch) obs_batch[brow] = s;  // the observation this action was sampled on
+      if (obs_batch) wd_store_untracked(obs_batch + brow, s);  // the observation this action was sampled on
       t += 1;
       const bool terminated = cp_euler(s, a, p);
       const bool fin = (t == episode_length) || terminated;
       if (obs_batch) {
-        action_batch[brow] = a;
-        reward_batch[brow] = 1.0f;
-        done_batch[brow] = fin ? 1 : 0;
+        wd_store_untracked(action_batch + brow, a);
+        wd_store_untracked(reward_batch + brow, 1.0f);
+        wd_store_untracked(done_batch + brow, fin ? 1 : 0);
       }
+      // (untracked stores, wd_common.h: a store the compiler tracks inside the loop costs a wait for ALL stores on
+      // every trip, executed or not.  The one place that reads such an address back -- the restore of a replica whose
+      // reset rows were not preloaded -- drains the counter itself first.)
       if (!obs_batch || k == ticks - 1 || fin) {
-        action_arr[env] = a;
-        observation_arr[env] = s;
-        reward_arr[env] = 1.0f;
-        done_arr[env] = fin ? 1 : 0;
+        wd_store_untracked(action_arr + env, a);
+        wd_store_untracked(observation_arr + env, s);
+        wd_store_untracked(reward_arr + env, 1.0f);
+        wd_store_untracked(done_arr + env, fin ? 1 : 0);
       }
-      if (fin || k == ticks - 1) state_arr[env] = s;  // otherwise the state stays in registers
+      if (fin || k == ticks - 1) wd_store_untracked(state_arr + env, s);  // otherwise the state stays in registers
       // ---- reset in place (reset.cu:9-75 for every registered array); `_done_` stays set
       if (fin) {
-        for (int r = 0; r < n_reset_arrays; ++r) {
-          const CpResetEntry ent = table[r];
-          const long base = (long)env * ent.row_elems;
-          for (int i = 0; i < ent.row_elems; ++i) ent.data[base + i] = ent.ref[base + i];
-        }
         t = 0;
-        s = state_arr[env];
-        // the reload is consumed HERE, inside the rare branch: otherwise the wait for it lands at the top
-        // of the tick loop, where it also waits for every store of the previous tick
-        asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w));
+        if (cached) {  // stores only
+          // (after the untracked stores above to the same rows: stores of one wavefront to one address stay in order)
+          wd_store_untracked((float4 *)ent0.data + env, make_float4(__uint_as_float(row0.x), __uint_as_float(row0.y), __uint_as_float(row0.z), __uint_as_float(row0.w)));
+          if (n_reset_arrays == 2)
+            wd_store_untracked((float4 *)ent1.data + env, make_float4(__uint_as_float(row1.x), __uint_as_float(row1.y), __uint_as_float(row1.z), __uint_as_float(row1.w)));
+          const uint4 sr = ((size_t)ent0.data == (size_t)state_arr) ? row0 : row1;
+          s = make_float4(__uint_as_float(sr.x), __uint_as_float(sr.y), __uint_as_float(sr.z), __uint_as_float(sr.w));
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the untracked stores above have left
+          for (int r = 0; r < n_reset_arrays; ++r) {
+            const CpResetEntry ent = table[r];
+            const long base = (long)env * ent.row_elems;
+            for (int i = 0; i < ent.row_elems; ++i) ent.data[base + i] = ent.ref[base + i];
+          }
+          s = state_arr[env];
+          // the reload is consumed HERE, inside the rare branch: otherwise the wait for it lands at the top
+          // of the tick loop, where it also waits for every store of the previous tick
+          asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w));
+        }
       }
     }
     env_timestep_arr[env] = t;

@@ -109,9 +109,9 @@ struct TcArgs {
 
 // extra inputs of the fused rollout tick (sample both action heads -> step -> reset finished
 // replicas, ONE launch)
-struct TcResetEntry {  // same layout as wd_reset_entry in wd_core.hip
-  uint32_t *data;
-  const uint32_t *ref;
+struct TcResetEntry {  // same layout as wd_reset_entry in wd_core.hip (global pointers: wd_common.h, wd_global_u32)
+  wd_global_u32 *data;
+  const wd_global_u32 *ref;
   int row_elems;
   int pad_;
 };

@@ -86,9 +86,50 @@ __device__ __forceinline__ wd_u4 wd_philox4x32_10(wd_u4 ctr, uint32_t k0, uint32
   return ctr;
 }
 
+// The draw of the fused ticks of SINGLE-head envs (TagGridWorld, Cartpole): the 32 random bits of (row, epoch) are
+// word (epoch & 3) of the Philox block with counter (row, epoch >> 2, stream tag, 4), so a launch that runs T ticks
+// pays one Philox call (~100 instructions, 40 of them quarter-rate integer multiplies) per FOUR ticks -- the block
+// is cached in registers (`blk`, `blk_quad`; start with blk_quad = 0xffffffff) -- and T single-tick launches draw
+// exactly what one T-tick launch draws.  (TagContinuous' two heads share one block per tick: words 0 and 1 of
+// counter (row, epoch, stream tag, 3).)  Restated in oracle/core_np.py::single_head_tick_uniform.
+__device__ __forceinline__ uint32_t wd_tick_draw(uint32_t row, uint32_t epoch, uint32_t stream_tag, uint32_t k0, uint32_t k1,
+                                                 wd_u4 &blk, uint32_t &blk_quad) {
+  const uint32_t quad = epoch >> 2;
+  if (quad != blk_quad) {
+    blk = wd_philox4x32_10(wd_u4{row, quad, stream_tag, 4u}, k0, k1);
+    blk_quad = quad;
+  }
+  const uint32_t w = epoch & 3u;
+  return (w == 0u) ? blk.x : (w == 1u) ? blk.y : (w == 2u) ? blk.z : blk.w;
+}
+
 // uniform in (0, 1], 24 random bits  (curand_uniform's range, random.cu:72)
 __device__ __forceinline__ float wd_u01_open_closed(uint32_t bits) {
   return (float)((bits >> 8) + 1u) * 0x1.0p-24f;
+}
+
+// A pointer that was READ FROM A TABLE in memory (the reset descriptors) is a generic pointer to the compiler: every
+// access through it is a FLAT instruction, whose completion is counted by both memory counters -- waiting for a flat
+// load then waits for every global store in flight as well.  The tables only ever hold device-memory addresses: say so.
+typedef uint32_t __attribute__((address_space(1))) wd_global_u32;
+
+// Global stores the compiler does NOT track, for the record stores inside a T-tick loop.  The waitcnt pass protects
+// the address / data registers of a store until the memory counter says it has left; a loop body that reuses those
+// registers on every trip therefore waits for the previous trip's stores (~1 us per tick: the whole cost of a
+// Cartpole or TagGridWorld tick).  The hardware reads a store's operands when it issues it (the write-through
+// flush of the TagContinuous rows relies on the same), so the registers can be rewritten at once; the s_nop covers
+// the one documented hazard (a VALU write to the data registers of a store of more than 64 bits in the next cycle).
+// Only for addresses this wavefront does not read back before the kernel ends.
+__device__ __forceinline__ void wd_store_untracked(int *p, int v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wd_store_untracked(float *p, float v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wd_store_untracked(float4 *p, float4 v) {
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  const v4f_ q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
 }
 
 // RNG state layout in HBM (uint32 words): [0]=seed lo, [1]=seed hi, [2]=n_threads,

@@ -231,9 +231,9 @@ __global__ void undo_done_flag_and_reset_timestep(int *done, int *timestep, int 
 // and (optionally) clears done/timestep -- the reference issues one launch per array
 // plus one for undo, 13 for TagContinuous (pycuda_function_manager.py:686-753).
 // `table` = n_arrays entries of {data, ref, row_elems}.
-struct wd_reset_entry {
-  uint32_t *data;
-  const uint32_t *ref;
+struct wd_reset_entry {  // (global pointers: wd_common.h, wd_global_u32)
+  wd_global_u32 *data;
+  const wd_global_u32 *ref;
   int row_elems;
   int pad_;
 };

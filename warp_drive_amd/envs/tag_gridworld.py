@@ -165,7 +165,7 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         timestep / done, and the [epb * N, F] observation image"""
         A = epb * self.num_agents
         F = 4 * self.num_agents + 1 if self.use_full_observation else 6
-        tables = (4 * (4 * A + 2 * epb) + 15) // 16 * 16   # the image starts 16-byte aligned (read as float4)
+        tables = (4 * (4 * A + 2 * epb + 2) + 15) // 16 * 16   # positions, time steps, done + 2 vote flags; the image starts 16-byte aligned (read as float4)
         with_image = tables + 4 * A * F
         return with_image if with_image <= 60000 else tables  # WD_GW_IMAGE_MAX_BYTES
 
@@ -202,7 +202,7 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
 
             E, N, T = int(dm.meta_info("n_envs")), self.num_agents, int(self.ticks_per_launch)
             F = 4 * N + 1 if self.use_full_observation else 6
-            assert int(probabilities[0].shape[-1]) <= 8 and 4 * (4 * epb * N + 2 * epb + epb * N * F) <= 60000, \
+            assert int(probabilities[0].shape[-1]) <= 8 and self.lds_bytes(epb) > 4 * epb * N * F and len(self.step_actions) == 5, \
                 "the rollout kernel needs the LDS observation image and at most 8 actions"
             want = {"obs": ((E, N, F), torch.float32), "actions": ((E, N, 1), torch.int32),
                     "rewards": ((E, N), torch.float32), "done": ((E,), torch.int32)}
@@ -210,7 +210,16 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
                 t = batch[key]
                 assert t.is_cuda and t.is_contiguous() and t.dtype == dtype and t.shape[0] >= T and \
                     tuple(t.shape[1:]) == shape, (key, tuple(t.shape), t.dtype)
-            args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"]]
+            # the rows finished replicas are restored from are kept in LDS for the whole launch (no loads inside the
+            # tick loop): the sum of the registered arrays' row lengths per replica, 0 = no room
+            cache_dwords = sum(int(np.prod(dm.get_shape(k)[1:])) for k in dm.reset_data_list)
+            lds = self.lds_bytes(epb)
+            if lds + 4 * epb * cache_dwords <= 60000:
+                lds += 4 * epb * cache_dwords
+            else:
+                cache_dwords = 0
+            args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"], np.int32(cache_dwords)]
+            return fm.get_function(name), args, block, grid, lds
         return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
 
     def step(self, actions=None):
