@@ -307,3 +307,24 @@ _GW_ROW_REBUILD = [(GW, "        if (use_full_observation) {\n          // Only 
                     "        s_fx[li] = fx;\n        s_fy[li] = fy;")]
 SETS["gw"] = {"base": [], "nocache": _GW_NOCACHE, "philox_every_tick": _GW_PHILOX_EVERY_TICK, "row_rebuild": _GW_ROW_REBUILD,
               "all_old": _GW_NOCACHE + _GW_PHILOX_EVERY_TICK + _GW_ROW_REBUILD}
+
+
+# ---- round 4: are the tracked stores of the move / sampling phases followed by waits for them?  (the waitcnt pass
+# protects a store's operand registers until the memory counter drains: the T-tick rollouts lost ~1 us per tick to that)
+_TC_UNTRACKED = [
+    (TC, "  a.loc_x[gi] = px;\n  a.loc_y[gi] = py;\n  a.speed[gi] = v;\n  a.direction[gi] = dir;\n  a.acceleration[gi] = acc;\n  a.edge_pen_arr[gi] = m.edge_pen;",
+     "  wd_store_untracked(a.loc_x + gi, px);\n  wd_store_untracked(a.loc_y + gi, py);\n  wd_store_untracked(a.speed + gi, v);\n"
+     "  wd_store_untracked(a.direction + gi, dir);\n  wd_store_untracked(a.acceleration + gi, acc);\n  wd_store_untracked(a.edge_pen_arr + gi, m.edge_pen);"),
+    (TC, "    if ((in.cleared != 0) != (sg == 0)) a.obs_rows_cleared[gi] = sg ? 0 : 1;", "    if ((in.cleared != 0) != (sg == 0)) wd_store_untracked(a.obs_rows_cleared + gi, sg ? 0 : 1);"),
+    (TC, "      a.timestep[env] = t;\n      tb.tstep[el] = t;\n      tb.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474",
+     "      wd_store_untracked(a.timestep + env, t);\n      tb.tstep[el] = t;\n      tb.tfrac[el] = (float)((double)t / (double)a.T);  // float(t) / episode_length, :474"),
+]
+SETS["tc_untracked"] = {"base": [], "untracked": _TC_UNTRACKED}
+
+
+# ---- round 4: ten blocks per CU instead of eight (LDS <= 16 KB per block: 11 staging rows per wavefront instead of 19).
+# At 2000 replicas a CU holds 7.8 blocks anyway; at 8000 / 16000 the blocks run in rounds and a block's lifetime is the
+# same 28 us whether its neighbours are in step with it or not (profiles/r04_phase_profile_E16000_t300.txt), so the
+# number of resident blocks is what bounds the throughput there.  Run with experiments/occupancy_variant.py (it sets the
+# host's staging target to the same value).
+SETS["occupancy"] = {"base": [], "lds16k": [(TC, "#define WD_TC_STAGE_TARGET 5400", "#define WD_TC_STAGE_TARGET 3300")]}

@@ -57,7 +57,8 @@ def test_code_object_has_all_kernels(built):
                                              "HipTagContinuousStep_K10", "HipClassicControlCartPoleEnvStep",
                                              "testkernel", "kIndexToActionArr", "wd_test_math", "HipTagContinuousTick_K10",
                                              "HipTagContinuousTick", "HipTagGridWorldTick",
-                                             "HipClassicControlCartPoleEnvTick"]
+                                             "HipClassicControlCartPoleEnvTick", "HipTagGridWorldRollout",
+                                             "HipTagContinuousStep_K10_N1024", "HipTagContinuousTick_K16_N1024"]
     for name in wanted:
         assert name.encode() in blob, f"{name} is not in the code object"
     assert b"gfx950" in blob

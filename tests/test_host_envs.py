@@ -60,3 +60,38 @@ def test_tag_continuous_cpu_backend(golden_dir, tag):
             assert bool(done["__all__"]) == bool(d["done"][t, i])
             if done["__all__"]:
                 e.reset()
+
+
+def test_tag_continuous_picks_the_entry_point_by_agent_count_and_k():
+    """the fast-path specialisations: K <= 32 up to 512 agents, the `_N1024` entries (K <= 16) for 513 .. 1024 agents,
+    the generic entry for full observations and for what no specialisation covers
+    (csrc/kernels/tag_continuous.hip: WD_TC_SPECIALISE / WD_TC_SPECIALISE_BIG)"""
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+
+    def name(runners, K, full=False):
+        env = TagContinuous(num_taggers=5, num_runners=runners, use_full_observation=full, num_other_agents_observed=K,
+                            seed=1)
+        return env.resolve_step_function_name("HipTagContinuousStep")
+
+    assert name(100, 10) == "HipTagContinuousStep_K10"
+    assert name(100, 9) == "HipTagContinuousStep_K10" and name(100, 11) == "HipTagContinuousStep_K12"
+    assert name(500, 32) == "HipTagContinuousStep_K32" and name(100, 33) == "HipTagContinuousStep"
+    assert name(600, 10) == "HipTagContinuousStep_K10_N1024" and name(1019, 3) == "HipTagContinuousStep_K4_N1024"
+    assert name(1000, 16) == "HipTagContinuousStep_K16_N1024" and name(1000, 17) == "HipTagContinuousStep"
+    assert name(100, 10, full=True) == "HipTagContinuousStep"
+
+
+def test_tag_continuous_lds_fits_a_workgroup_up_to_1024_agents():
+    """the fused tick's LDS image: both probability slabs up to 256 agents, ONE slab beyond (the heads are sampled one
+    after the other): 1005 agents with 21-way heads fit a workgroup's 160 KB, 41-way heads do not"""
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+
+    def lds(runners, levels):
+        env = TagContinuous(num_taggers=5, num_runners=runners, use_full_observation=False, num_other_agents_observed=10,
+                            num_acceleration_levels=levels, num_turn_levels=levels, seed=1)
+        n = env.num_agents
+        return env.lds_bytes(1, fused=True, threads=(n + 63) // 64 * 64)
+
+    assert lds(100, 20) <= 20480              # eight blocks per CU at the BASELINE shape
+    assert lds(500, 20) <= 80 * 1024          # two blocks per CU at ~510 agents (one slab: 42 KB, not 85)
+    assert lds(1000, 20) <= 160 * 1024 < lds(1000, 40)

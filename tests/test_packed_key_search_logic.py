@@ -158,3 +158,144 @@ def test_many_candidates_within_a_few_hundred_ulps():
         answered += 1
         assert got == _reference(x, y, sig, 0, K), (trial, m.tolist(), order.tolist())
     assert answered > 50 and fell_back > 50
+
+
+# ---------------------------------------------------------------- round 4: the shortcut for an isolated close pair, the
+# merge of two wavefronts' key lists, the zone the exact resolution scans (tc_resolve_keys, tc_merge_sorted,
+# tc_zone_resolve in csrc/kernels/tag_continuous.hip), for 7 / 9 / 10 id bits
+def _packed_r4(x, y, sig, i, K, idb=7):
+    """as _packed, plus: a lane that is not `apart` whose close gaps (< 3 * 2^idb - 1) are ISOLATED pairs -- no two
+    adjacent, and not the pair at the cut together with the pair behind it -- settles each pair with one exact
+    (float32 distance, index) compare.  -> (ids, how) with how in {"chain", "pairs", "ranking"}; None = exact resolution."""
+    N, idm = len(x), (1 << idb) - 1
+    d2 = _d2(x, y, i)
+    d2[sig == 0] = np.inf
+    keys = (d2.view(np.uint32) & ~np.uint32(idm)) | np.arange(N, dtype=np.uint32)
+    S = np.sort(keys)[:K + 3].astype(np.int64)
+    S = np.concatenate([S, np.full(K + 3 - len(S), 0xFFFFFFFF, np.int64)])
+    o = list(S)
+    if i in o:
+        o.remove(i)
+    o = np.array(o[:K + 2], dtype=np.int64)
+    thr = 3 * (idm + 1) - 1
+    d = np.sqrt(d2).astype(f32)
+    if min(int(o[k + 1] - o[k]) for k in range(K)) >= thr and o[K - 1] < INVALID:
+        return [int(v & idm) for v in o[:K]], "chain"
+    if o[K - 1] < INVALID:
+        close = [int(o[k + 1] - o[k]) < thr for k in range(K + 1)]  # pair (k, k + 1); k == K: behind the cut
+        rel = close[:K]
+        runs = any(rel[k] and rel[k + 1] for k in range(K - 1)) or (rel[K - 1] and close[K])
+        if not runs:
+            ids = [int(v & idm) for v in o[:K + 1]]
+            for q in range(K):
+                if rel[q]:
+                    a, b = ids[q], ids[q + 1]
+                    if (d[b], b) < (d[a], a):
+                        ids[q], ids[q + 1] = b, a
+            return ids[:K], "pairs"
+    got = _packed(x, y, sig, i, K) if idb == 7 else None
+    return (got, "ranking") if got is not None else None
+
+
+def _check_r4(x, y, sig, K, stats, idb=7):
+    for i in range(len(x)):
+        if not sig[i]:
+            continue
+        got = _packed_r4(x, y, sig, i, K, idb)
+        if got is None:
+            stats["resolve"] += 1
+            # what the exact resolution scans: every candidate in the key buckets <= bucket(K-th other) + 1 -- the
+            # reference's K nearest must all be among them
+            idm = (1 << idb) - 1
+            d2 = _d2(x, y, i)
+            d2[sig == 0] = np.inf
+            bucket = d2.view(np.uint32).astype(np.int64) >> idb
+            others = [j for j in range(len(x)) if j != i and sig[j]]
+            kth_key = sorted(((int(d2[j].view(np.uint32)) & ~idm) | j) for j in others)[K - 1]
+            zone = {j for j in others if bucket[j] <= (kth_key >> idb) + 1}
+            want = _reference(x, y, sig, i, K)
+            assert set(want) <= zone and len(zone) >= K
+            continue
+        ids, how = got
+        stats[how] += 1
+        want = _reference(x, y, sig, i, K)
+        assert ids == want + [-1] * (K - len(want)), (i, how, ids, want)
+
+
+@pytest.mark.parametrize("N,K,idb", [(105, 10, 7), (40, 6, 7), (128, 16, 7), (300, 10, 9), (700, 8, 10)])
+def test_isolated_close_pairs_are_settled_by_one_compare(N, K, idb):
+    rng = np.random.default_rng(N * 31 + K)
+    stats = {"chain": 0, "pairs": 0, "ranking": 0, "resolve": 0}
+    for trial in range(12 if N <= 128 else 3):
+        L = f32(20.0)
+        if trial % 3 == 0:
+            x, y = rng.random(N) * L, rng.random(N) * L
+        elif trial % 3 == 1:
+            c = rng.integers(0, 4, N)
+            x = (c % 2) * 10 + rng.normal(0, 1e-3, N)
+            y = (c // 2) * 10 + rng.normal(0, 1e-3, N)
+        else:
+            x, y = rng.random(N) * L, rng.random(N) * L
+            x[rng.random(N) < 0.4] = L
+            y[rng.random(N) < 0.3] = 0
+        sig = (rng.random(N) < 0.85).astype(np.int32)
+        _check_r4(x.astype(f32), y.astype(f32), sig, K, stats, idb)
+    assert stats["pairs"] > 0 and stats["chain"] > 0, stats
+
+
+@pytest.mark.parametrize("swap", [0, 1])
+@pytest.mark.parametrize("idb", [7, 9, 10])
+def test_a_lone_close_pair_anywhere_in_the_list_takes_the_shortcut(swap, idb):
+    K, N = 6, 14
+    ulp4 = np.spacing(f32(4.0))
+    w = 1 << idb
+    how_seen = set()
+    for pos in range(0, K + 2):
+        for delta in (0, 1, 2, w - 1, w, w + 1, 2 * w - 1, 2 * w, 2 * w + 1, 3 * w - 2, 3 * w - 1, 3 * w, 4 * w, 10 * w):
+            b = f32(np.sqrt(np.float64(delta) * np.float64(ulp4)))
+            x = [8.0] + [8.0 + 0.2 * (j + 1) for j in range(pos)]
+            y = [8.0] * (pos + 1)
+            pair = [(10.0, 8.0), (6.0, float(f32(8.0) + b))]
+            for px, py in (pair[::-1] if swap else pair):
+                x.append(px); y.append(py)
+            while len(x) < N:
+                x.append(8.0 + 3.0 + 0.37 * len(x)); y.append(8.0)
+            x, y = np.array(x, f32), np.array(y, f32)
+            got = _packed_r4(x, y, np.ones(N, np.int32), 0, K, idb)
+            assert got is not None and got[1] in ("chain", "pairs"), (pos, delta, got)
+            assert got[0] == _reference(x, y, np.ones(N, np.int32), 0, K), (pos, delta, swap, idb)
+            how_seen.add(got[1])
+    assert how_seen == {"chain", "pairs"}
+
+
+def _merge_sorted(S, P):
+    """tc_merge_sorted: both lists padded to a power of two with 0xffffffff, c[k] = min(S[k], P[W-1-k]), bitonic merge"""
+    L = len(S)
+    W = 8 if L <= 8 else 16 if L <= 16 else 32 if L <= 32 else 64
+    pad = 0xFFFFFFFF
+    s = list(S) + [pad] * (W - L)
+    p = list(P) + [pad] * (W - L)
+    c = [min(s[k], p[W - 1 - k]) for k in range(W)]
+    stride = W // 2
+    while stride >= 1:
+        for k in range(W):
+            if (k & stride) == 0:
+                lo, hi = min(c[k], c[k + stride]), max(c[k], c[k + stride])
+                c[k], c[k + stride] = lo, hi
+        stride //= 2
+    return c[:L]
+
+
+@pytest.mark.parametrize("L", [5, 13, 15, 19, 27, 35])
+def test_two_wavefronts_key_lists_merge_to_the_single_chain_result(L):
+    """wavefront 0 chains the first half of the candidates, wavefront 1 the second half; the L smallest of the union
+    of their L-entry lists are exactly the L smallest of all candidates, in order"""
+    rng = np.random.default_rng(L)
+    for trial in range(300):
+        n = int(rng.integers(2, 64))
+        keys = rng.choice(1 << 30, size=n, replace=False).astype(np.int64)
+        half = ((n + 7) >> 3) << 2
+        a, b = np.sort(keys[:half])[:L], np.sort(keys[half:])[:L]
+        pad = lambda v: list(v) + [0xFFFFFFFF] * (L - len(v))
+        want = pad(np.sort(keys)[:L])
+        assert _merge_sorted(pad(a), pad(b)) == want
