@@ -13,8 +13,8 @@
 //
 // Two implementations share the move / reward code:
 //
-//   tc_fast_impl<KMAX>   N <= 512 agents per replica, K <= KMAX <= 32 observed neighbours
-//     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>).
+//   tc_fast_impl<KMAX>   N <= 1024 agents per replica, K <= KMAX <= 32 observed neighbours (K <= 16 beyond 512 agents)
+//     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>, ..._K<k>_N1024 beyond 512 agents).
 //     block = `epb` whole replicas (105 agents -> 1 replica on 128 threads), thread = agent.
 //       fetch    every global LOAD of the tick is issued first (state, step rewards, time step, action
 //                tables; the memory counters return in order, so a load issued later would wait for all
@@ -34,8 +34,11 @@
 //                K+3 smallest keys; where the first K+1 keys are far enough apart the chain order
 //                is the reference's order and the ids are read off the keys, otherwise the exact
 //                (sqrt(d^2), id) keys of the first K(+1) entries are ranked by pairwise
-//                compare-and-count; ~1e-7 of the agents repeat the search with the two-pass one
-//                (tc_knn_registers: exact K-th distance, compare-mask pass, id-ordered peeling);
+//                compare-and-count -- an ISOLATED close pair by one exact compare of the two (round 4);
+//                ~1e-7 of the agents repeat the search with the two-pass one (tc_knn_registers: exact K-th
+//                distance, compare-mask pass, id-ordered peeling) or, beyond 128 candidates, have the whole
+//                wavefront resolve the zone around the cut (tc_zone_resolve).  While at most 64 agents are in
+//                the game both wavefronts of a block chain half of the candidates each (tc_merge_sorted);
 //       ids out  packed indices -> agent ids through an LDS table; 16-bit block-local ids per agent
 //                row in LDS (entry k -> slot k; out-of-order lanes rewrite their rows by rank); one
 //                block barrier; nearest_neighbor_ids rows are converted from them and stored;
@@ -49,7 +52,7 @@
 //                `*_at_reset` copies.
 //     Wave priority falls with the phase (s_setprio 3, 2, 0), so the wavefronts of a SIMD finish together.
 //
-//   tc_generic_impl      any N <= 1024, any K, full observations (entry points
+//   tc_generic_impl      full observations, or K beyond the specialisations (any N <= 1024; entry points
 //     HipTagContinuousStep / HipTagContinuousTick): K-pass selection per agent, observation
 //     rows written from a block-strided (row, slot) loop (16-byte stores in the
 //     full-observation mode).
