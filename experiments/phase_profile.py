@@ -61,21 +61,19 @@ drv.synchronize()
 st = raw.reshape(-1, SLOTS).astype(np.int64)
 ran = st[:, 15] > 0
 searched = st[:, 9] > 0
-flags = st[:, 18]
-print(f"wavefronts: {ran.sum()}; ran the search: {searched.sum()}; without a bound at the start: {(flags & 0xff > 0).sum()}; "
-      f"list overflow: {((flags >> 8) & 0xff > 0).sum()}; bound check failed: {((flags >> 16) > 0).sum()}; "
-      f"with a lane in the two-pass fallback: {(st[:, 20] > 0).sum()}; with a lane whose close pair was settled by one exact compare: "
+print(f"wavefronts: {ran.sum()}; ran the search: {searched.sum()}; with a lane in the two-pass fallback / whole-wavefront resolution: "
+      f"{(st[:, 20] > 0).sum()}; with a lane whose close pair was settled by one exact compare: "
       f"{(st[:, 23] > 0).sum()}; with a lane in the full ranking: {(st[:, 22] > 0).sum()}")
-pre = searched & (st[:, 8] > 0)
+pre = searched & (st[:, 19] > 0)   # (replicas of more than 128 agents: the prefiltered search; 1 = its radius held, 2 = repeated with the full chain)
 if pre.any():
-    tr = st[pre, 19]
-    print(f"prefiltered wavefronts: {pre.sum()}; pass-2 trips (4 candidates each) mean {tr.mean():.2f} p50 {np.percentile(tr, 50):.0f} "
-          f"p99 {np.percentile(tr, 99):.0f} max {tr.max()}")
+    tr = st[pre, 18]
+    print(f"prefiltered wavefronts: {pre.sum()}; radius check failed: {(st[pre, 19] == 2).sum()}; chain trips (pass 2) mean {tr.mean():.1f} "
+          f"p50 {np.percentile(tr, 50):.0f} p99 {np.percentile(tr, 99):.0f} max {tr.max()}")
 # phases a wavefront skipped inherit the previous stamp (duration 0)
 for k in range(1, 16):
     st[:, k] = np.where(st[:, k] > 0, st[:, k], st[:, k - 1])
-names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "search: bound", "search: pass 1 (list)",
-         "search: chain (pass 2 / full)", "search: keys resolved", "search: ids, remember", "id rows + barrier + nearest ids flushed",
+names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "search: radius", "search: prefiltered chain",
+         "search: full chain", "search: keys resolved", "search: ids, remember", "id rows + barrier + nearest ids flushed",
          "obs gathered+flushed", "barrier3", "rewards/end"]
 for wv, label in ((0, "wave 0 of each block"), (WPB - 1, "the last wave of each block")):
     s = st[wv::WPB]

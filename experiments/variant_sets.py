@@ -328,3 +328,7 @@ SETS["tc_untracked"] = {"base": [], "untracked": _TC_UNTRACKED}
 # number of resident blocks is what bounds the throughput there.  Run with experiments/occupancy_variant.py (it sets the
 # host's staging target to the same value).
 SETS["occupancy"] = {"base": [], "lds16k": [(TC, "#define WD_TC_STAGE_TARGET 5400", "#define WD_TC_STAGE_TARGET 3300")]}
+
+
+# ---- round 4: the prefiltered search of replicas of more than 128 agents on / off ("nopre" = the full chain, as before)
+SETS["prefilter_big"] = {"base": [], "pop2": [(TC, "constexpr int POPS = (IDB == 10) ? 1 : 2;", "constexpr int POPS = 2;")], "nopre": [(TC, "constexpr bool PRE = (IDB != 7) && (KMAX <= 12);", "constexpr bool PRE = false;")]}

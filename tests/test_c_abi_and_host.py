@@ -58,7 +58,8 @@ def test_code_object_has_all_kernels(built):
                                              "testkernel", "kIndexToActionArr", "wd_test_math", "HipTagContinuousTick_K10",
                                              "HipTagContinuousTick", "HipTagGridWorldTick",
                                              "HipClassicControlCartPoleEnvTick", "HipTagGridWorldRollout",
-                                             "HipTagContinuousStep_K10_N1024", "HipTagContinuousTick_K16_N1024"]
+                                             "HipTagContinuousStep_K10_N1024", "HipTagContinuousTick_K16_N1024",
+                                             "HipTagContinuousStep_K32_N512", "HipTagContinuousTick_K10_N512"]
     for name in wanted:
         assert name.encode() in blob, f"{name} is not in the code object"
     assert b"gfx950" in blob

@@ -420,7 +420,7 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     assert near_tie <= max(2, rows // 100000), (near_tie, rows)
 
 
-def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed):
+def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed, kernel="HipTagContinuousTick_K10", before_tick=None):
     """The fused tick (sample + step + reset in one launch) with the benchmark's uniform policy, every tick
     compared with the C oracle: sampled actions replayed, then state / observations / rewards / done /
     nearest_neighbor_ids and the post-reset state.  Returns (mean live agents per tick, id rows compared,
@@ -442,11 +442,13 @@ def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed):
     create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
                                       push_data_batch_placeholders=False)
     engine = RolloutEngine(w, sampler)  # uniform probabilities: the benchmark's policy
-    assert engine.step_kernel_name == "HipTagContinuousTick_K10"
+    assert engine.step_kernel_name == kernel
     orc = TagContinuousCOracle(E, n_threads=min(16, os.cpu_count() or 1), **cfg)
     N = orc.N
     live_seen, near_tie, rows, id_rows, id_pads = [], 0, 0, 0, 0
     for t in range(ticks):
+        if before_tick is not None:
+            before_tick(t, w)
         engine.run(1)
         torch.cuda.synchronize()
         orc.step(pull(w, "sampled_actions"))
@@ -502,6 +504,44 @@ def test_arena_empties_below_K_agents_at_the_headline_shape():
     # (tick 110 is the first of the next episode: everybody is back; a fifth of the arena then empties it again fast)
     assert min(live_seen[60:110]) < 14 and live_seen[110] > 95, (live_seen[60:110:10], live_seen[108:113])
     assert id_pads > 500, id_pads  # rows with fewer than K others in the game were compared
+
+
+@pytest.mark.parametrize("runners,taggers,tagging_distance,kernel", [(600, 10, 0.14, "HipTagContinuousTick_K10_N1024"),
+                                                                     (300, 6, 0.12, "HipTagContinuousTick_K10_N512")])
+def test_prefiltered_search_of_big_replicas(runners, taggers, tagging_distance, kernel):
+    """Replicas of more than 128 agents search their neighbours inside a radius derived from the previous tick's
+    neighbours (`knn_prev`, tc_chain_prefiltered) while at least 200 agents are in the game.  70 ticks of a 45-tick
+    episode with a tagging distance that takes the arena from full to under 200 agents (prefilter on, then off) and
+    back to full at the restart, every tick against the C oracle incl. nearest_neighbor_ids.  The hint is ONLY a
+    hint: it is overwritten with random bits, with zeros (everybody remembers agents 0, 0, 0 ...), with one far
+    agent and with "none" along the way -- the results must not move."""
+    from tests.hip_harness import pull
+
+    cfg = dict(BENCH_CFG, num_taggers=taggers, num_runners=runners, grid_length=30.0, tagging_distance=tagging_distance,
+               episode_length=45)
+    rng = np.random.default_rng(runners)
+    hints = []
+    N = runners + taggers
+
+    def scribble(t, w):
+        shape = w.cuda_data_manager.get_shape("knn_prev")
+        if t > 0:
+            hints.append(pull(w, "knn_prev").copy())
+        if t == 3:
+            _push_state(w, knn_prev=rng.integers(-2**31, 2**31, size=shape, dtype=np.int64).astype(np.int32))
+        elif t == 6:
+            _push_state(w, knn_prev=np.zeros(shape, np.int32))
+        elif t == 9:
+            _push_state(w, knn_prev=np.full(shape, (N - 1) * 0x10001, np.int32))
+        elif t == 12:
+            _push_state(w, knn_prev=np.full(shape, -1, np.int32))
+
+    live_seen, id_rows, _, rows = _fused_ticks_vs_c_oracle(cfg, 3, 70, 11, kernel=kernel, before_tick=scribble)
+    # the prefilter was on (at least 200 agents in the game) through the scribbles, then off, then on again after the restart
+    assert live_seen[0] == N and live_seen[13] > 200 > min(live_seen[:45]) and live_seen[46] > 200, live_seen[:50:5]
+    # the kernel did remember neighbours (valid 16-bit ids) while the prefilter was on
+    h = hints[1].view(np.uint16).reshape(3, N, 16)
+    assert ((h[..., :13] < N).sum(axis=-1) >= 12).mean() > 0.4, "knn_prev was not written"
 
 
 def _push_state(w, **arrays):
@@ -639,8 +679,8 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
                                                   (525, 5, False), (1020, 3, False), (1000, 10, False), (700, 16, False),
                                                   (600, 20, False)])
 def test_many_agents_paths(n_runners, K, full_obs):
-    """replicas of more than 128 agents: with partial observations up to 512 agents take the fast path with 9 id bits
-    in the search keys (blocks of up to eight wavefronts), 513 .. 1024 agents the `_N1024` entries (10 id bits, blocks
+    """replicas of more than 128 agents: with partial observations up to 512 agents take the `_N512` entries (9 id bits
+    in the search keys, blocks of up to eight wavefronts), 513 .. 1024 agents the `_N1024` entries (10 id bits, blocks
     of up to sixteen wavefronts, K <= 16); full observations and K > 16 beyond 512 agents take the generic entry
     points (tc_generic_impl: K-pass selection, one block of up to 1024 threads per replica)"""
     cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=30.0, episode_length=6, seed=13,
@@ -652,7 +692,8 @@ def test_many_agents_paths(n_runners, K, full_obs):
     name = TagContinuous(**cfg).resolve_step_function_name("HipTagContinuousStep")
     N = 4 + n_runners
     want = ("HipTagContinuousStep" if (full_obs or (N > 512 and K > 16)) else
-            f"HipTagContinuousStep_K{min(k for k in (4, 8, 10, 12, 16) if k >= K)}_N1024" if N > 512 else None)
+            f"HipTagContinuousStep_K{min(k for k in (4, 8, 10, 12, 16) if k >= K)}_N1024" if N > 512 else
+            f"HipTagContinuousStep_K{min(k for k in (2, 4, 6, 8, 10, 12, 16, 24, 32) if k >= K)}_N512")
     assert want is None or name == want, (name, want)
     _run_lockstep(cfg, E=3, ticks=8, seed=n_runners)
 

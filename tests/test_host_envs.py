@@ -63,7 +63,7 @@ def test_tag_continuous_cpu_backend(golden_dir, tag):
 
 
 def test_tag_continuous_picks_the_entry_point_by_agent_count_and_k():
-    """the fast-path specialisations: K <= 32 up to 512 agents, the `_N1024` entries (K <= 16) for 513 .. 1024 agents,
+    """the fast-path specialisations: K <= 32 up to 128 agents and (`_N512`) up to 512, the `_N1024` entries (K <= 16) for 513 .. 1024 agents,
     the generic entry for full observations and for what no specialisation covers
     (csrc/kernels/tag_continuous.hip: WD_TC_SPECIALISE / WD_TC_SPECIALISE_BIG)"""
     from warp_drive_amd.envs.tag_continuous import TagContinuous
@@ -75,7 +75,8 @@ def test_tag_continuous_picks_the_entry_point_by_agent_count_and_k():
 
     assert name(100, 10) == "HipTagContinuousStep_K10"
     assert name(100, 9) == "HipTagContinuousStep_K10" and name(100, 11) == "HipTagContinuousStep_K12"
-    assert name(500, 32) == "HipTagContinuousStep_K32" and name(100, 33) == "HipTagContinuousStep"
+    assert name(123, 10) == "HipTagContinuousStep_K10" and name(124, 10) == "HipTagContinuousStep_K10_N512"
+    assert name(500, 32) == "HipTagContinuousStep_K32_N512" and name(100, 33) == "HipTagContinuousStep"
     assert name(600, 10) == "HipTagContinuousStep_K10_N1024" and name(1019, 3) == "HipTagContinuousStep_K4_N1024"
     assert name(1000, 16) == "HipTagContinuousStep_K16_N1024" and name(1000, 17) == "HipTagContinuousStep"
     assert name(100, 10, full=True) == "HipTagContinuousStep"

@@ -173,6 +173,16 @@ def _packed_r4(x, y, sig, i, K, idb=7):
     keys = (d2.view(np.uint32) & ~np.uint32(idm)) | np.arange(N, dtype=np.uint32)
     S = np.sort(keys)[:K + 3].astype(np.int64)
     S = np.concatenate([S, np.full(K + 3 - len(S), 0xFFFFFFFF, np.int64)])
+    got = _decide_from_list_r4(S, d2, i, K, idb)
+    if got is not None:
+        return got
+    got = _packed(x, y, sig, i, K) if idb == 7 else None
+    return (got, "ranking") if got is not None else None
+
+
+def _decide_from_list_r4(S, d2, i, K, idb):
+    """what tc_resolve_keys reads off the key list without the ranking: (ids, "chain" | "pairs") or None"""
+    idm = (1 << idb) - 1
     o = list(S)
     if i in o:
         o.remove(i)
@@ -193,8 +203,7 @@ def _packed_r4(x, y, sig, i, K, idb=7):
                     if (d[b], b) < (d[a], a):
                         ids[q], ids[q + 1] = b, a
             return ids[:K], "pairs"
-    got = _packed(x, y, sig, i, K) if idb == 7 else None
-    return (got, "ranking") if got is not None else None
+    return None
 
 
 def _check_r4(x, y, sig, K, stats, idb=7):
@@ -299,3 +308,57 @@ def test_two_wavefronts_key_lists_merge_to_the_single_chain_result(L):
         pad = lambda v: list(v) + [0xFFFFFFFF] * (L - len(v))
         want = pad(np.sort(keys)[:L])
         assert _merge_sorted(pad(a), pad(b)) == want
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the PREFILTERED search of replicas of more than 128 agents (tc_knn_bound16 / tc_chain_prefiltered).
+# Only candidates inside a radius derived from the previous tick's neighbours reach the chain; the radius is a
+# heuristic, what makes the result exact is the check that the K-th other agent found lies at least two key buckets
+# inside it (then everything that was left out is past the buckets the decision rule above looks at).
+def _prefiltered_keys(x, y, i, T, K, idb):
+    """the chain's list when only candidates with d2 <= T are inserted; None when the radius check fails"""
+    N = len(x)
+    idm = np.uint32((1 << idb) - 1)
+    d2 = _d2(x, y, i)
+    keys = (d2.view(np.uint32) & ~idm) | np.arange(N, dtype=np.uint32)
+    listed = np.sort(keys[d2 <= T])[:K + 3].astype(np.int64)
+    S = np.concatenate([listed, np.full(K + 3 - len(listed), 0x7F800000 | N, np.int64)])  # (lanes that ran out insert the pad)
+    sK = int(S[K])  # entry K with the agent's own entry in the list = the K-th other agent
+    Tb = int(np.array([T], f32).view(np.uint32)[0])
+    if (sK >> idb) + 2 > (Tb >> idb):
+        return None
+    return S
+
+
+@pytest.mark.parametrize("N,K,idb", [(300, 10, 9), (1000, 10, 10), (600, 4, 10), (1000, 12, 10)])
+def test_prefiltered_list_gives_the_full_chain_result_whenever_the_radius_check_holds(N, K, idb):
+    rng = np.random.default_rng(N + K)
+    held = failed = decided = 0
+    for trial in range(6):
+        x = rng.uniform(0, 30, N).astype(f32)
+        y = rng.uniform(0, 30, N).astype(f32)
+        if trial >= 3:  # clustered: many near-equal distances
+            x = (np.round(x * 2) / 2).astype(f32)
+            y = (np.round(y * 2) / 2).astype(f32)
+        sig = np.ones(N, np.int32)
+        for i in rng.choice(N, 12, replace=False):
+            d2 = _d2(x, y, i)
+            order = np.argsort(d2, kind="stable")
+            for scale in (0.5, 0.9, 1.0, 1.0000001, 1.15, 2.0):  # radii below, at and above the K-th neighbour
+                T = f32(d2[order[K]] * f32(scale))
+                S = _prefiltered_keys(x, y, i, T, K, idb)
+                if S is None:
+                    failed += 1
+                    continue
+                held += 1
+                # every key the decision rule can look at is the same as in the full chain's list ...
+                idm = np.uint32((1 << idb) - 1)
+                full = np.sort((d2.view(np.uint32) & ~idm) | np.arange(N, dtype=np.uint32))[:K + 3].astype(np.int64)
+                cut = (int(S[K]) >> idb) + 2
+                assert [k for k in full if (k >> idb) < cut] == [k for k in S if (k >> idb) < cut]
+                # ... and what it decides from the prefiltered list is the reference's answer (or a fallback)
+                got = _decide_from_list_r4(S, d2, i, K, idb)
+                if got is not None:
+                    assert got[0] == _reference(x, y, sig, i, K), (i, scale, got)
+                    decided += 1
+    assert held > 20 and failed > 10 and decided > 10, (held, failed, decided)

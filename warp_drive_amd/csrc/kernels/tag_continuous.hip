@@ -108,6 +108,10 @@ struct TcArgs {
   int *obs_rows_cleared;  // [E, N] 1 = the agent's observation row in HBM is all zeros already: rows of agents out
                           // of the game are zeros until the episode restarts (:476-560), so the sparse form of the
                           // row gather clears such a row ONCE instead of rewriting it every tick
+  unsigned *knn_prev;     // [E, N, 8] 32 bytes per agent (replicas of more than 128 agents; else unused): the ids (16 bits
+                          // each, 0xffff = none) of the K + 3 nearest other agents of the previous tick in search order
+                          // -- the hint the prefiltered neighbour search starts from (tc_knn_bound16); any content is
+                          // safe (the radius is checked); may be null
 };
 
 // extra inputs of the fused rollout tick (sample both action heads -> step -> reset finished
@@ -881,6 +885,169 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
   for (int k = 0; k < L; ++k) S[k] = c[k];
 }
 
+// ---- PREFILTERED search for replicas of more than 128 agents (round 4; one replica per block, K <= 12, used while at
+// least WD_TC_PRE_MIN_LIVE agents are in the game).  The chain costs 13 median-of-three (~3 cycles each with the VALU
+// saturated) + 6 cheap instructions per candidate and searcher and is VALU-bound on all sixteen wavefronts of a
+// 1005-agent replica: 80 % of its tick.  Agents move little per tick, so the searcher's K + 3 nearest others of the
+// PREVIOUS tick (32 bytes per agent in HBM, `knn_prev`) give a radius that holds the K nearest now (tc_knn_bound16):
+//   pass 1  every candidate: squared distance and ONE compare against the radius, shifted into a per-lane bit mask
+//           (v_cmp + v_addc: mask = 2 mask + bit) -- 7 instructions, 5 of them float32 add / mul at ~1.2 cycles;
+//   pass 2  the candidates whose bit is set (~15 per lane) go through the chain: 128 candidates = four mask words at
+//           a time, word by word every lane pops its own lowest set bit (lanes that ran out insert the pad position
+//           at +inf), as many trips as the fullest lane of the wavefront needs, U candidates per trip with the
+//           next trip's positions in flight.
+// At ~100 candidates this was measured and NOT adopted (a wash: pass 2 does not shrink with the number of
+// candidates); the break-even is at a few hundred.  What comes out is what the full chain
+// gives: every candidate within four key buckets of the radius is listed, so tc_resolve_keys sees the same first
+// K + 1 keys, and beyond them keys that are more than four buckets past the K-th (they cannot matter) or nothing.
+// That the radius really held the K nearest is CHECKED afterwards (the K-th other agent found must lie inside it), so
+// the content of `knn_prev` is only a hint: stale, restored or overwritten rows cost time (the wavefront repeats the
+// search with the full chain), never exactness.
+#define WD_TC_PRE_MIN_LIVE 200
+
+// The radius: 1.15 x (K + 3) / n x the LARGEST current squared distance to the n remembered agents that are still in
+// the game (their positions read NaN otherwise: v_max_f32 skips a NaN); none when fewer than 5 are.  With all K + 3 in
+// the game this lists a few more than K + 3 candidates, so the chain refills the remembered set with the K + 3 nearest
+// every tick; after remembered agents were tagged out the radius grows by the share that is missing.  A heuristic on
+// purpose (the radius that provably holds K candidates lists about K of them, leaves no spares to remember, and the
+// next tag leaves a stand-in from across the arena as the bound: experiments/offline/knn_prefilter_sim2.py), checked by
+// the caller.  Returns the bits of the radius, 0x7f800000 = none.
+template <int KMAX>
+__device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int pad_id, float xi, float yi, uint4 pa, uint4 pb,
+                                                   int K) {
+  constexpr int M = KMAX + 3;
+  float2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14;
+#define WD_TC_PREV_POS(k, vec, word) \
+  if (k < M) p##k = xy_by_id[min((vec.word >> (16 * (k & 1))) & 0xffffu, (unsigned)pad_id)]  // out of the game / none / garbage: NaN
+  WD_TC_PREV_POS(0, pa, x); WD_TC_PREV_POS(1, pa, x); WD_TC_PREV_POS(2, pa, y); WD_TC_PREV_POS(3, pa, y);
+  WD_TC_PREV_POS(4, pa, z); WD_TC_PREV_POS(5, pa, z); WD_TC_PREV_POS(6, pa, w); WD_TC_PREV_POS(7, pa, w);
+  WD_TC_PREV_POS(8, pb, x); WD_TC_PREV_POS(9, pb, x); WD_TC_PREV_POS(10, pb, y); WD_TC_PREV_POS(11, pb, y);
+  WD_TC_PREV_POS(12, pb, z); WD_TC_PREV_POS(13, pb, z); WD_TC_PREV_POS(14, pb, w);
+#undef WD_TC_PREV_POS
+  float far = 0.0f;
+  unsigned n = 0u;
+#define WD_TC_PREV_DIST(k)                                                                                  \
+  if (k < M) {                                                                                              \
+    const float dx = xi - p##k.x, dy = yi - p##k.y;                                                         \
+    const float d2 = dx * dx + dy * dy;                                                                     \
+    far = fmaxf(far, d2); /* (maxnum: a NaN operand is ignored) */                                          \
+    asm("v_cmp_o_f32 vcc, %1, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(d2) : "vcc");       \
+  }
+  WD_TC_PREV_DIST(0) WD_TC_PREV_DIST(1) WD_TC_PREV_DIST(2) WD_TC_PREV_DIST(3) WD_TC_PREV_DIST(4)
+  WD_TC_PREV_DIST(5) WD_TC_PREV_DIST(6) WD_TC_PREV_DIST(7) WD_TC_PREV_DIST(8) WD_TC_PREV_DIST(9)
+  WD_TC_PREV_DIST(10) WD_TC_PREV_DIST(11) WD_TC_PREV_DIST(12) WD_TC_PREV_DIST(13) WD_TC_PREV_DIST(14)
+#undef WD_TC_PREV_DIST
+  const float T = far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
+  return (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;
+}
+
+// S: the L smallest keys among the candidates with d2 <= Tf, ascending; returns the (L+1)-th (one more id to remember)
+template <int L, int IDB, int U>
+__device__ __forceinline__ unsigned tc_chain_prefiltered(const float2 *cxy, float xi, float yi, int N, float Tf, int pad_idx,
+                                                         unsigned (&S)[L]) {
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+  unsigned extra = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
+#define WD_TC_MASK_PUSH(m, d2v) \
+  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(Tf) : "vcc")
+#define WD_TC_MASK_PUSH4(m, grp)                                       \
+  do {                                                                 \
+    float d_[4];                                                       \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                    \
+      const float dx = xi - (grp).p[u].x, dy = yi - (grp).p[u].y;      \
+      d_[u] = dx * dx + dy * dy;                                       \
+    }                                                                  \
+    WD_TC_MASK_PUSH(m, d_[0]); WD_TC_MASK_PUSH(m, d_[1]);              \
+    WD_TC_MASK_PUSH(m, d_[2]); WD_TC_MASK_PUSH(m, d_[3]);              \
+  } while (0)
+#define WD_TC_POP2(ix, px)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+    const bool have_ = (mw != 0u);                                                             \
+    ix[u] = have_ ? (unsigned)(top - (__ffs(mw) - 1)) : (unsigned)pad_idx;                     \
+    mw &= mw - 1u;                                                                             \
+    px[u] = cxy[ix[u]];                                                                        \
+  }
+#ifdef WD_TC_PROBES
+  int probe_trips = 0;
+#endif
+  for (int c0 = 0; c0 < N; c0 += 128) {  // wave-uniform
+    // ---- pass 1 of this chunk: candidate b of word w (candidates c0 + 32 w .. + nb - 1) ends on bit nb - 1 - b
+    unsigned mask[4] = {0u, 0u, 0u, 0u};
+    TcP4 ga = tc_load4(cxy, c0), gb;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = c0 + 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int nb = min(32, N - j0);
+        unsigned mu = 0u;
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {  // two groups of four per trip, ping-pong
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_MASK_PUSH4(mu, ga);
+          ga = tc_load4(cxy, j0 + b + 8);  // (at most 8 entries past the last candidate: padding)
+          WD_TC_MASK_PUSH4(mu, gb);
+        }
+        if (b + 4 <= nb) {
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_MASK_PUSH4(mu, ga);
+          ga = gb;
+          b += 4;
+        }
+        for (; b < nb; ++b) {  // (only the last word can have a remainder)
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
+          const float d2 = dx * dx + dy * dy;
+          WD_TC_MASK_PUSH(mu, d2);
+        }
+        mask[w] = mu;
+      }
+    }
+    // ---- pass 2 of this chunk
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = c0 + 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int top = j0 + min(32, N - j0) - 1;  // the candidate on bit 0
+        unsigned mw = mask[w];
+        unsigned idx[U], idn[U];
+        float2 pj[U], pn[U];
+        bool more = __ballot(mw != 0u) != 0ull;  // wave-uniform: as many trips as the fullest lane needs
+        if (more) {
+          WD_TC_POP2(idn, pn);
+          while (more) {
+#ifdef WD_TC_PROBES
+            ++probe_trips;
+#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) { idx[u] = idn[u]; pj[u] = pn[u]; }
+            more = __ballot(mw != 0u) != 0ull;
+            if (more) { WD_TC_POP2(idn, pn); }
+            asm volatile("" ::: "memory");  // (keeps the reads above the work below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const float dx = xi - pj[u].x, dy = yi - pj[u].y;
+              const float d2 = dx * dx + dy * dy;
+              const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx[u];
+              extra = tc_umed3(S[L - 1], extra, key_);
+#pragma unroll
+              for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
+              S[0] = min(S[0], key_);
+            }
+          }
+        }
+      }
+    }
+  }
+#ifdef WD_TC_PROBES
+  WD_TC_PROBE_VAL(18, probe_trips);
+#endif
+#undef WD_TC_POP2
+#undef WD_TC_MASK_PUSH4
+#undef WD_TC_MASK_PUSH
+  return extra;
+}
+
 // ---- exact resolution for ONE searcher by the WHOLE wavefront (replicas of more than 128 agents; the K-pass scan
 // above took ~1.5 ms for a 1005-agent replica -- ten times the rest of the tick -- and a launch of 2000 replicas hit it
 // in ~11 wavefronts, so the launch waited for it on every tick).  The chain already located the cut: the answer lies
@@ -947,15 +1114,23 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   // drop the agent's own entry (d2 = 0 exactly: key == ag).  It is the first entry unless a twin with
   // a lower id sits on the same spot.
-  if (__ballot(S[0] != (unsigned)ag) == 0ull) {  // wave-uniform
+  // (values first: with two producers of S -- the full and the prefiltered chain -- a select between two ELEMENTS of S
+  // becomes a select between their addresses, which keeps the two elements in scratch memory for the whole search)
+  unsigned sv[L];
 #pragma unroll
-    for (int k = 0; k < L - 1; ++k) o[k] = S[k + 1];
+  for (int k = 0; k < L; ++k) {
+    sv[k] = S[k];
+    asm volatile("" : "+v"(sv[k]));
+  }
+  if (__ballot(sv[0] != (unsigned)ag) == 0ull) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < L - 1; ++k) o[k] = sv[k + 1];
   } else {
     bool after = false;
 #pragma unroll
     for (int k = 0; k < L - 1; ++k) {
-      after = after || (S[k] == (unsigned)ag);
-      o[k] = after ? S[k + 1] : S[k];
+      after = after || (sv[k] == (unsigned)ag);
+      o[k] = after ? sv[k + 1] : sv[k];
     }
   }
   // Chain order IS the reference's order wherever neighbouring keys are >= 383 apart: then their
@@ -1449,6 +1624,18 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     }
     my_c = before + __popcll(live_mask & ((1ull << lane) - 1ull));
   }
+  // the prefiltered search (tc_chain_prefiltered): on for big replicas while enough agents are in the game
+  constexpr bool PRE = (IDB != 7) && (KMAX <= 12);
+  bool pre_on = false;  // block-uniform
+  uint4 hint_a = make_uint4(~0u, ~0u, ~0u, ~0u), hint_b = hint_a;
+  if constexpr (PRE) {
+    pre_on = compact && (a.knn_prev != nullptr) && (n_live >= WD_TC_PRE_MIN_LIVE) && (l.stage_dwords >= 512);
+    if (pre_on && active && in.sg != 0) {  // (in flight during the move)
+      const uint4 *const h = (const uint4 *)(a.knn_prev + (size_t)(env * N + ag) * 8);
+      hint_a = h[0];
+      hint_b = h[1];
+    }
+  }
 
   // ------------------------------------------------------------ move
   float edge_pen = 0.0f, my_x = 0.0f, my_y = 0.0f;
@@ -1459,13 +1646,25 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     edge_pen = m.edge_pen; my_x = m.x; my_y = m.y;
     // agents out of the game are pushed to +BIG for the neighbour search only; every other
     // consumer (taggers are never out of the game) reads real positions
-    l.xy[el * NP + ag] = make_float2(sg ? m.x : WD_BIG, m.y);
+    // (with the prefilter on: NaN -- only its bound reads the entry of an agent that is out of the game then)
+    l.xy[el * NP + ag] = make_float2(sg ? m.x : (PRE && pre_on ? __builtin_nanf("") : WD_BIG), m.y);
     if (compact) {
       if (sg) {
         l.xyc[my_c] = make_float2(m.x, m.y);
         l.cid[1 + my_c] = (short)ag;
+        if (PRE && pre_on) {  // the hint goes to the lane that searches for this agent: slot my_c & 63 of wavefront my_c >> 6
+          uint4 *const slot = (uint4 *)(l.stage + (size_t)(my_c >> 6) * l.stage_dwords) + 2 * (my_c & 63);
+          slot[0] = hint_a;
+          slot[1] = hint_b;
+        }
       }
-      if (ag == 0) l.cid[0] = -1;
+      if (ag == 0) {
+        l.cid[0] = -1;
+        if (PRE && pre_on) {
+          l.xyc[n_live] = make_float2(WD_BIG, WD_BIG);         // the pad candidate of pass 2: a position at +inf
+          l.xy[N] = make_float2(__builtin_nanf(""), 0.0f);     // what a remembered id of 0xffff (none) reads
+        }
+      }
     }
     tc_feat_store(l.feat, li, m.ft);
     // bit 0: in the game before this tick's tagging; bit 1: the observation row in HBM is all zeros already
@@ -1518,7 +1717,38 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const int j_half = split ? (((n_live + 7) >> 3) << 2) : n_cand;        // first candidate of wavefront 1's half
   const bool helper = split && (wave == 1);                               // wave-uniform
   unsigned S[L];
-  if (searcher || (helper && lane < n_live)) {
+  bool prefiltered = false;           // wave-uniform
+  unsigned extra = 0xffffffffu;       // the (L+1)-th key (prefiltered search only)
+  if constexpr (PRE) {
+    if (pre_on) {  // block-uniform
+      unsigned Tb = 0u;
+      float sx = 0.0f, sy = 0.0f;
+      if (searcher) {
+        const uint4 *const slot = (const uint4 *)stage + 2 * lane;
+        const uint4 pa = slot[0], pb = slot[1];
+        sx = sxy[ag].x; sy = sxy[ag].y;
+        Tb = tc_knn_bound16<KMAX>(l.xy, N, sx, sy, pa, pb, K);
+      }
+      WD_TC_PROBE(7);
+      if (__ballot(searcher && Tb == 0x7f800000u) == 0ull) {  // every searcher of the wavefront has a radius
+        // (lanes without a searcher: radius -1, nothing listed; they only take part in the wave-wide votes)
+        // (candidates popped per trip: the fullest lane of a 32-candidate word holds ~2 at 1000 agents, ~4 at 500)
+        constexpr int POPS = (IDB == 10) ? 1 : 2;
+        extra = tc_chain_prefiltered<L, IDB, POPS>(sxy, sx, sy, n_cand, searcher ? __uint_as_float(Tb) : -1.0f, n_cand, S);
+        // the radius held the K nearest iff the K-th other agent found (entry K with the agent's own) lies at least
+        // two key buckets inside it: everything that was not listed is then past the buckets tc_resolve_keys looks at
+        unsigned sK = S[KMAX];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) sK = (k == K) ? S[k] : sK;
+        const bool held = (sK >> IDB) + 2u <= (Tb >> IDB);
+        prefiltered = __ballot(searcher && !held) == 0ull;
+        WD_TC_PROBE_VAL(19, prefiltered ? 1 : 2);
+        if (!prefiltered) extra = 0xffffffffu;
+      }
+      WD_TC_PROBE(8);
+    }
+  }
+  if (!prefiltered && (searcher || (helper && lane < n_live))) {
     // one pass with packed keys (this wavefront's share of the candidates)
     const int me = helper ? lane : ag;
     tc_chain_range<L, IDB>(sxy, sxy[me].x, sxy[me].y, helper ? j_half : 0, helper ? n_cand : j_half, S);
@@ -1553,6 +1783,26 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
 #pragma unroll
       for (int k = 0; k < KMAX - 1; ++k) oKth = (k == K - 1) ? o[k] : oKth;
       zone_hi = (oKth >> IDB) + 1u;
+    }
+    if constexpr (PRE) {
+      if (pre_on) {  // remember the K + 3 nearest others (agent ids, 16 bits each; 0xffff = none) for the next tick's radius
+        unsigned w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          unsigned pair = 0u;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int k = 2 * q + h;
+            const unsigned key = (k < L - 1) ? o[k < L - 1 ? k : 0] : (k == L - 1) ? extra : 0xffffffffu;
+            const unsigned id = (key >= 0x7f800000u) ? 0xffffu : (unsigned)(unsigned short)l.cid[1 + (key & ((1u << IDB) - 1u))];
+            pair |= id << (16 * h);
+          }
+          w[q] = pair;
+        }
+        uint4 *const h = (uint4 *)(a.knn_prev + (size_t)(env * N + l.cid[1 + ag]) * 8);
+        h[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        h[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
     }
     if (!exact && (IDB == 7 || n_cand <= 128)) {
       WD_TC_PROBE_VAL(20, 1);
@@ -1998,7 +2248,8 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
       int *num_runners_arr, float kDistanceMarginForReward, float kTagRewardForTagger,            \
       float kTagPenaltyForRunner, float kEndOfGameRewardForRunner, int *done_arr,                 \
       int *env_timestep_arr, int kNumAgents, int kEpisodeLength, int kNumEnvs,                    \
-      int kNumAccelerationActions, int kNumTurnActions, int *obs_rows_cleared_arr, int kEnvBegin
+      int kNumAccelerationActions, int kNumTurnActions, int *obs_rows_cleared_arr,                 \
+      unsigned *knn_prev_arr, int kEnvBegin
 
 #define WD_TC_PACK()                                                                              \
   TcArgs a;                                                                                       \
@@ -2015,6 +2266,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   a.tag_penalty = kTagPenaltyForRunner; a.end_reward = kEndOfGameRewardForRunner;                 \
   a.done = done_arr; a.timestep = env_timestep_arr; a.N = kNumAgents; a.T = kEpisodeLength;       \
   a.E = kNumEnvs; a.env_begin = kEnvBegin; a.obs_rows_cleared = obs_rows_cleared_arr;              \
+  a.knn_prev = knn_prev_arr;                                                                      \
   (void)neighbor_distances_arr; (void)neighbor_ids_sorted_by_distance_arr;
 
 // Fused rollout tick: sample both action heads + step + reset finished replicas in ONE launch
@@ -2046,23 +2298,34 @@ __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
   tc_generic_impl<true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
-// fast entries (N <= 512, partial observations, K <= KM); the host picks the smallest KM >= K.  Replicas of
-// more than 128 agents (blocks of up to eight wavefronts) take the copy with 9 id bits in the search keys
+// fast entries (partial observations, K <= KM); the host picks the smallest KM >= K and the entry for the replica size:
+// `_K<KM>` up to 128 agents (7 id bits in the search keys), `_K<KM>_N512` for 129 .. 512 (blocks of up to eight
+// wavefronts, 9 id bits), `_K<KM>_N1024` beyond.  Separate entries, so that work on the big-replica search never moves
+// the registers or the code layout of the headline kernel.
 #define WD_TC_SPECIALISE(KM, WAVES)                                                                 \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
-    if (a.N > 128) tc_fast_impl<KM, false, false, 9>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else if (a.K == KM) tc_fast_impl<KM, false, true, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    if (a.K == KM) tc_fast_impl<KM, false, true, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
     else tc_fast_impl<KM, false, false, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }                                                                                            \
   __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
     WD_TC_PACK();                                                                              \
     WD_TC_FUSE_PACK();                                                                         \
-    if (a.N > 128) tc_fast_impl<KM, true, false, 9>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else if (a.K == KM) tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    if (a.K == KM) tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
     else tc_fast_impl<KM, true, false, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+  }                                                                                            \
+  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM##_N512(WD_TC_PARAMS) {     \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    tc_fast_impl<KM, false, false, 9>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+  }                                                                                            \
+  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM##_N512(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
+    WD_TC_PACK();                                                                              \
+    WD_TC_FUSE_PACK();                                                                         \
+    tc_fast_impl<KM, true, false, 9>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
   }
 // replicas of 513 .. 1024 agents: blocks of up to sixteen wavefronts (1024 threads: the reference's default geometry
 // serves up to 1024 agents per block, managers/function_manager.py:64-67), 10 id bits in the search keys (buckets of

@@ -275,6 +275,15 @@ class TagContinuous(CUDAEnvironmentContext):
         # gather clears them once instead of rewriting them every tick (device-side bookkeeping; restored with
         # the other arrays at a reset)
         feed.add_data(name="obs_rows_cleared", data=np.zeros((n,), dtype=np.int32), save_copy_and_apply_at_reset=True)
+        # Replicas of more than 128 agents: the ids (16 bits each, 0xffff = none) of every agent's K + 3 nearest
+        # others of the previous tick, 32 bytes per agent -- the hint the prefiltered neighbour search starts from
+        # (tc_chain_prefiltered in the kernel file).  Only a hint: the kernel checks the radius it derives from it, so
+        # the content never changes a result.  (Registered like per-replica state, which is what makes the wrapper
+        # allocate one copy per replica; a reset then restores "none", and the first tick of the new episode searches
+        # without a radius.)
+        big = self._fast_path() and n > 128
+        feed.add_data(name="knn_prev", data=np.full((n, 8) if big else (1, 8), -1, dtype=np.int32),
+                      save_copy_and_apply_at_reset=True)
         feed.add_data(name="runner_exits_game_after_tagged", data=self.runner_exits_game_after_tagged)
         feed.add_data(name="still_in_the_game", data=self.still_in_the_game, save_copy_and_apply_at_reset=True)
         return feed
@@ -293,7 +302,7 @@ class TagContinuous(CUDAEnvironmentContext):
         "nearest_neighbor_ids", _REWARDS, "step_rewards", "num_runners", "distance_margin_for_reward",
         "tag_reward_for_tagger", "tag_penalty_for_runner", "end_of_game_reward_for_runner", "_done_",
         "_timestep_", ("n_agents", "meta"), ("episode_length", "meta"), ("n_envs", "meta"),
-        "num_acceleration_actions", "num_turn_actions", "obs_rows_cleared",
+        "num_acceleration_actions", "num_turn_actions", "obs_rows_cleared", "knn_prev",
     ]  # + kEnvBegin appended by step_launch / tick_launch
 
     FAST_PATH_MAX_AGENTS = 1024  # tc_fast_impl: 7 id bits in the search keys up to 128 agents, 9 up to 512 (blocks of up to
@@ -314,7 +323,7 @@ class TagContinuous(CUDAEnvironmentContext):
         big = self.num_agents > 512
         for k in (self._K_SPECIALISATIONS_N1024 if big else _K_SPECIALISATIONS):
             if k >= self.num_other_agents_observed:
-                return f"{default_name}_K{k}" + ("_N1024" if big else "")
+                return f"{default_name}_K{k}" + ("_N1024" if big else "_N512" if self.num_agents > 128 else "")
         return default_name
 
     def lds_bytes(self, epb, fused=False, threads=None):
