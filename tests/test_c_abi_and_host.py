@@ -63,6 +63,12 @@ def test_code_object_has_all_kernels(built):
     for name in wanted:
         assert name.encode() in blob, f"{name} is not in the code object"
     assert b"gfx950" in blob
+    # shape-specialised kernels live in their own code objects (warp_drive_amd/build.py EXTRA_UNITS)
+    from warp_drive_amd.managers import hip_driver
+
+    for path, names in zip(hip_driver.EXTRA_HSACO_PATHS, (["HipTagGridWorldRollout_N5"],)):
+        extra = open(path, "rb").read()
+        assert all(n.encode() in extra for n in names) and b"gfx950" in extra, path
 
 
 def test_no_silent_cpu_fallback(built):

@@ -176,13 +176,16 @@ def test_gridworld_fused_tick(full_obs, E):
     assert finished >= 2 * E
 
 
-@pytest.mark.parametrize("full_obs,E,ticks", [
-    (True, 1000, 16), (False, 77, 9),
+@pytest.mark.parametrize("full_obs,E,ticks,general", [
+    (True, 1000, 16, False), (True, 1000, 16, True), (False, 77, 9, True),
     # 51 replicas per 256-thread block (an ODD count: the tables in front of the LDS observation image are then
     # 8 bytes past a 16-byte boundary) and a last block of 36 replicas, whose slice is a multiple of 16 bytes
     # and leaves through the float4 record path
-    (True, 513 * 51 + 36, 4)])
-def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
+    (True, 513 * 51 + 36, 4, True),
+    # the specialised kernel at a size whose row stride is NOT a multiple of 16 bytes (the record path falls back to
+    # 4-byte stores on three ticks of four) with a last block of 7 replicas, several blocks per CU
+    (True, 12 * 2600 + 7, 5, False)])
+def test_gridworld_rollout_records_every_tick(full_obs, E, ticks, general):
     """HipTagGridWorldRollout: T ticks of a fixed-policy rollout in one launch.  Row k of the env-level batch
     tensors is tick k: the observation the actions were sampled on, the actions (draw for draw: the Philox draw of
     tick k of T single-tick launches), the rewards and the done flag, replayed through the oracle (integer moves and
@@ -200,6 +203,8 @@ def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
                use_full_observation=full_obs)
     w = _mk(cfg, E)
     w.env.ticks_per_launch = ticks
+    if general:  # (5 agents with full observations would take HipTagGridWorldRollout_N5)
+        w.env.SPECIALISED_ROLLOUT = False
     N = w.n_agents
     F = 4 * N + 1 if full_obs else 6
     sampler = HIPSampler(w.cuda_function_manager)
@@ -211,8 +216,10 @@ def test_gridworld_rollout_records_every_tick(full_obs, E, ticks):
              "rewards": torch.full((ticks, E, N), -1.0, device="cuda"),
              "done": torch.full((ticks, E), -1, dtype=torch.int32, device="cuda")}
     engine = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch)
-    assert engine.fused and engine.step_kernel_name == "HipTagGridWorldRollout" and engine.ticks_per_launch == ticks
-    if E > 20000:
+    # 5 agents with full observations take the kernel specialised for that shape (blocks of one wavefront) unless told not to
+    want_kernel = "HipTagGridWorldRollout" if general else "HipTagGridWorldRollout_N5"
+    assert engine.fused and engine.step_kernel_name == want_kernel and engine.ticks_per_launch == ticks
+    if E > 20000 and general:
         assert w.env._geometry()[0] == 51
     ocfg = dict(cfg)
     ocfg.pop("seed")

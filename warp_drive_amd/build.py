@@ -4,6 +4,8 @@
                          libamdhip64 at run time, so it is NOT linked against it.
   csrc/wd_kernels.hsaco  gfx950 code object with every kernel of the rollout path,
                          loaded through wd_module_load().
+  csrc/wd_kernels_gw5.hsaco  shape-specialised kernels in their own code object (EXTRA_UNITS), loaded on
+                         demand: the TagGridWorld T-tick rollout for 5 agents / full observations.
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container;
 the built files are git-ignored but travel to the GPU box with the tree.
@@ -19,6 +21,9 @@ CSRC = os.path.join(HERE, "csrc")
 KDIR = os.path.join(CSRC, "kernels")
 LIB = os.path.join(CSRC, "libwdhip.so")
 HSACO = os.path.join(CSRC, "wd_kernels.hsaco")
+# translation units that are NOT part of wd_kernels.hip: each becomes its own code object, so that adding or
+# tuning a shape-specialised kernel leaves the main code object (and the counters collected on it) untouched
+EXTRA_UNITS = {"tag_gridworld_n5.hip": os.path.join(CSRC, "wd_kernels_gw5.hsaco")}
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 # -ffp-contract=off + correctly rounded div/sqrt are part of the parity contract
@@ -64,8 +69,15 @@ def build_runtime(force=False, verbose=False):
 
 
 def build_kernels(force=False, verbose=False, extra_flags=()):
-    srcs = [os.path.join(KDIR, f) for f in sorted(os.listdir(KDIR)) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(KDIR, f) for f in sorted(os.listdir(KDIR)) if f.endswith((".hip", ".h")) and f not in EXTRA_UNITS]
     srcs.append(os.path.abspath(__file__))  # the compiler flags live here
+    for unit, out in EXTRA_UNITS.items():
+        unit_srcs = [os.path.join(KDIR, unit), os.path.join(KDIR, "wd_common.h"), os.path.abspath(__file__)]
+        if force or not _newer(out, unit_srcs):
+            cmd = [_hipcc(), *KERNEL_FLAGS, *extra_flags, unit_srcs[0], "-o", out]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
     if not force and _newer(HSACO, srcs):
         return HSACO
     cmd = [_hipcc(), *KERNEL_FLAGS, *extra_flags, os.path.join(KDIR, "wd_kernels.hip"), "-o", HSACO]

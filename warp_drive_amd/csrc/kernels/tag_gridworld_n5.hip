@@ -1,0 +1,220 @@
+// tag_gridworld_n5.hip -- the TagGridWorld T-tick rollout (HipTagGridWorldRollout in tag_gridworld.hip) specialised
+// for the shape every BASELINE config uses: N = 5 agents (4 taggers + the runner), full observations (F = 21),
+// blocks of ONE wavefront = 12 replicas.  Its own code object (csrc/wd_kernels_gw5.hsaco): the host picks it when the
+// shape matches (envs/tag_gridworld.py::tick_launch), the general kernel serves everything else.
+//
+// Why: at BASELINE configs[1] (1000 replicas) the rollout is 84 single-wavefront blocks, one per CU -- a tick is one
+// wavefront's dependent chain (~530 instructions at ~5 cycles each, two block barriers, ~20 dependent LDS round
+// trips: 2.14 us per tick).  What a block of one wavefront does not need:
+//   * barriers and LDS vote flags: LDS operations of ONE wavefront execute in issue order, so a lane's read sees any
+//     earlier write of another lane; "did any replica finish" is a ballot;
+//   * positions in LDS for the tag check: the runner's cell reaches the replica's five lanes through one
+//     ds_bpermute, "some tagger stands on it" is a ballot + a shift;
+//   * the per-replica time step in LDS: every lane keeps its replica's in a register;
+//   * float divisions per tick (x / L, y / L, t / episode_length: ~15 instructions each, correctly rounded): all
+//     quotients that can occur are tabulated in LDS once per launch WITH THE SAME DIVISION, so the values are the
+//     reference's bit for bit (tag_gridworld.py:208-214, :273);
+//   * index arithmetic with runtime N, F, epb;
+//   * the mid-launch write of restored rows to the global arrays: this kernel writes the state after the last tick to
+//     every array it restores (positions, observations, time step), so only its LDS / register copies are restored
+//     inside the loop.  The host checks that the registered reset arrays are exactly those three.
+// Semantics, recording and random draws are those of HipTagGridWorldRollout (same arguments + the action table's
+// device address, which lives in the main code object); parity: tests/test_gpu_gridworld.py, same test, same oracle.
+#include "wd_common.h"
+
+namespace {
+
+struct Gw5ResetEntry {  // same layout as wd_reset_entry in wd_core.hip
+  wd_global_u32 *data;
+  const wd_global_u32 *ref;
+  int row_elems;
+  int pad_;
+};
+
+constexpr int GW5_N = 5, GW5_F = 21, GW5_EPB = 12;
+constexpr int GW5_ROW = GW5_N * GW5_F;        // 105 floats: one replica's observation rows
+constexpr int GW5_IMG = GW5_EPB * GW5_ROW;    // 1260 floats: the block's observation image
+constexpr int GW5_MAX_COORD = 63;             // cells per axis - 1 the quotient table (and the packed cell) holds
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
+    int *states_x_arr, int *states_y_arr, int *actions_arr, int *done_arr, float *rewards_arr, float *obs_arr,
+    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner, float step_cost_for_tagger,
+    int use_full_observation, int world_boundary, int *env_timestep_arr, int episode_length, int n_agents, int n_envs,
+    uint32_t *rng_state, const float *probs, int n_actions, const void *reset_table, int n_reset_arrays,
+    int stream_tag, int ticks, float *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
+    int reset_cache_dwords, const int *action_table) {
+  extern __shared__ __attribute__((aligned(16))) float gw5_smem[];
+  const int CD = reset_cache_dwords;                        // dwords per replica in the restore cache
+  float *const s_obs = gw5_smem;                            // [12][5][21] the block's observation image (16-byte aligned)
+  uint32_t *const s_cache = (uint32_t *)(s_obs + GW5_IMG);  // [12][CD] the rows finished replicas are restored from
+  float *const s_div = (float *)(s_cache + GW5_EPB * CD);   // [64] c / L
+  float *const s_tn = s_div + GW5_MAX_COORD + 1;            // [episode_length + 1] t / episode_length
+  const int lane = threadIdx.x;                             // (blocks are one wavefront)
+  const int el = lane / GW5_N, ag = lane - el * GW5_N;      // local replica (12 = none), agent
+  const Gw5ResetEntry *const table = (const Gw5ResetEntry *)reset_table;
+  const uint32_t k0 = rng_state[0], k1 = rng_state[1];
+  int act_dx[5], act_dy[5];  // the action table, once per launch (scalar registers)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { act_dx[i] = action_table[2 * i]; act_dy[i] = action_table[2 * i + 1]; }
+  {  // every quotient a tick can need, computed with the division the reference's expression compiles to
+    const float L = (float)world_boundary;
+    if (lane <= world_boundary) s_div[lane] = (float)lane / L;
+    for (int q = lane; q <= episode_length; q += 64) s_tn[q] = (float)q / (float)episode_length;
+  }
+
+  for (int env0 = blockIdx.x * GW5_EPB; env0 < n_envs; env0 += gridDim.x * GW5_EPB) {
+    const int env = env0 + el;
+    const bool active = (el < GW5_EPB) && (env < n_envs);
+    const int idx = env * GW5_N + ag;
+    const int envs_here = min(GW5_EPB, n_envs - env0);
+    const int n_out = envs_here * GW5_ROW;
+    float *const obs_blk = obs_arr + (long)env0 * GW5_ROW;
+    int x = 0, y = 0, t = 0;
+    uint32_t epoch0 = 0u;
+    wd_u4 blk = wd_u4{0u, 0u, 0u, 0u};  // the Philox block of four consecutive ticks (wd_tick_draw)
+    uint32_t blk_quad = 0xffffffffu;
+    float cumv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cumv[i] = 0.0f;
+    if (active) {
+      x = states_x_arr[idx];
+      y = states_y_arr[idx];
+      t = env_timestep_arr[env];
+      epoch0 = rng_state[WD_RNG_HEADER + idx];
+      const float *row = probs + (long)idx * n_actions;
+      float cum = 0.0f;  // the running float32 sums of the (fixed) probabilities, once per launch
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < n_actions) cum = (i == 0) ? row[0] : cum + row[i];
+        cumv[i] = cum;
+      }
+    }
+    for (int q = lane; q < n_out; q += 64) s_obs[q] = obs_blk[q];  // the observation the first action is sampled on
+    // the rows finished replicas are restored from: per registered array one flat, coalesced copy of the block's rows
+    int off_x = 0, off_y = 0, off_obs = 0;
+    {
+      int off = 0;
+      for (int r = 0; r < n_reset_arrays; ++r) {
+        const Gw5ResetEntry ent = table[r];
+        const int re = ent.row_elems;
+        if ((size_t)ent.data == (size_t)states_x_arr) off_x = off;
+        if ((size_t)ent.data == (size_t)states_y_arr) off_y = off;
+        if ((size_t)ent.data == (size_t)obs_arr) off_obs = off;
+        const wd_global_u32 *const src = ent.ref + (long)env0 * re;
+        const float inv_re = 1.0f / (float)re;
+        for (int q = lane; q < envs_here * re; q += 64) {
+          const int e = (int)(((float)q + 0.5f) * inv_re);  // q / re (exact for these sizes)
+          s_cache[e * CD + off + (q - e * re)] = src[q];
+        }
+        off += re;
+      }
+    }
+    __syncthreads();
+    // every value loaded above is consumed HERE: the wait for a load whose first use is inside the tick loop is placed
+    // inside the loop and -- the memory counter returns in order -- waits for the previous tick's stores on every trip
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(t), "+v"(epoch0));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(cumv[i]));
+    float last_reward = 0.0f;
+    int last_action = 0, last_done = 0;
+    float *const rep = s_obs + min(el, GW5_EPB - 1) * GW5_ROW;  // this lane's replica's five rows
+    const uint32_t *const my_cache = s_cache + min(el, GW5_EPB - 1) * CD;
+    const int runner_lane = min(el * GW5_N + GW5_N - 1, 63);
+
+    for (int k = 0; k < ticks; ++k) {
+      // ---- record the observation of this tick (flat, coalesced; none of the record stores is tracked).  The usual
+      // case -- the block's slice of the row is a whole number of 16-byte vectors on a 16-byte boundary -- reads its
+      // (up to) five vectors per lane with all LDS reads in flight, then stores them; a loop of read / wait / store
+      // is five LDS round trips one after the other
+      float *const brow = obs_batch + ((long)k * n_envs + env0) * GW5_ROW;
+      if ((((size_t)brow & 15) | (size_t)(n_out & 3)) == 0) {  // block-uniform
+        const int nvec = n_out >> 2;  // 315 for a full block
+        const float4 *const img4 = (const float4 *)s_obs;
+        float4 v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = img4[min(lane + 64 * i, GW5_IMG / 4 - 1)];  // (clamped into the image)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          if (lane + 64 * i < nvec) wd_store_untracked((float4 *)brow + lane + 64 * i, v[i]);
+      } else {
+        for (int q = lane; q < n_out; q += 64) wd_store_untracked(brow + q, s_obs[q]);
+      }
+      float rew = 0.0f;
+      int a = 0;
+      if (active) {
+        // ---- sample (random.cu:51-85), the draw of tick k of T single-tick launches
+        const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)idx, epoch0 + (uint32_t)k, (uint32_t)stream_tag, k0, k1,
+                                                        blk, blk_quad));
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cnt += (i < n_actions && cumv[i] < u) ? 1 : 0;
+        a = min(cnt, n_actions - 1);
+        wd_store_untracked(action_batch + ((long)k * n_envs * GW5_N + idx), a);
+        // ---- movement :152-173
+        int ddx = act_dx[0], ddy = act_dy[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) { ddx = (a == i) ? act_dx[i] : ddx; ddy = (a == i) ? act_dy[i] : ddy; }
+        const int ux = x + ddx, uy = y + ddy;
+        const int cx = min(max(ux, 0), world_boundary), cy = min(max(uy, 0), world_boundary);
+        if (ux != cx || uy != cy) rew = -wall_hit_penalty;
+        x = cx;
+        y = cy;
+        t += 1;  // :295
+      }
+      // ---- tag check :175-178: does a tagger stand on the runner's cell?  (all 64 lanes take part in the exchange)
+      const int cell = x | (y << 8);
+      const int runner_cell = __shfl(cell, runner_lane);
+      const unsigned long long on_runner = __ballot(active && (ag < GW5_N - 1) && (cell == runner_cell));
+      const bool tag = ((unsigned)(on_runner >> (min(el, GW5_EPB - 1) * GW5_N)) & 0xfu) != 0u;
+      const bool fin = active && ((t >= episode_length) || tag);  // :314
+      if (active) {
+        if (ag == 0) wd_store_untracked(done_batch + ((long)k * n_envs + env), fin ? 1 : 0);
+        last_done = fin ? 1 : 0;
+        const float base = (ag < GW5_N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
+                                            : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
+        wd_store_untracked(reward_batch + ((long)k * n_envs * GW5_N + idx), base + rew);
+        last_reward = base + rew;
+        last_action = a;
+        // ---- the image: only the positions and the time change from tick to tick (the type and "is me" columns are
+        // constants that arrived with the image and return with a restore); this lane's agent is column ag (x) and
+        // 5 + ag (y) of its replica's five rows, the time is column 20 of its own row
+        const float fx = s_div[x], fy = s_div[y], tnorm = s_tn[t];
+#pragma unroll
+        for (int i = 0; i < GW5_N; ++i) {
+          rep[i * GW5_F + ag] = fx;
+          rep[i * GW5_F + GW5_N + ag] = fy;
+        }
+        rep[ag * GW5_F + 4 * GW5_N] = tnorm;
+      }
+      // ---- restore finished replicas: register and LDS copies only (see the header)
+      unsigned long long fm = __ballot(fin);  // wave-uniform
+      if (fm == 0ull) continue;
+      if (fin) {
+        x = (int)my_cache[off_x + ag];
+        y = (int)my_cache[off_y + ag];
+        t = 0;
+      }
+      while (fm != 0ull) {
+        const int e = ((__ffsll((long long)fm) - 1) * 13) >> 6;  // lane / 5 for lanes < 64
+        fm &= ~(0x1full << (e * GW5_N));
+        for (int q = lane; q < GW5_ROW; q += 64) s_obs[e * GW5_ROW + q] = __uint_as_float(s_cache[e * CD + off_obs + q]);
+      }
+    }
+    // ---- what the launch leaves in the per-tick arrays: the state after its last tick
+    if (active) {
+      states_x_arr[idx] = x;
+      states_y_arr[idx] = y;
+      rewards_arr[idx] = last_reward;
+      actions_arr[idx] = last_action;
+      rng_state[WD_RNG_HEADER + idx] = epoch0 + (uint32_t)ticks;
+      if (ag == 0) {
+        done_arr[env] = last_done;
+        env_timestep_arr[env] = t;
+      }
+    }
+    for (int q = lane; q < n_out; q += 64) obs_blk[q] = s_obs[q];
+    __syncthreads();  // (the next trip overwrites the image and the cache)
+  }
+}

@@ -6,6 +6,8 @@ Host-side mirror of reference example_envs/tag_gridworld/tag_gridworld.py
 contract, same DataFeed registration; the device step launches the gfx950 kernel
 `HipTagGridWorldStep` (csrc/kernels/tag_gridworld.hip) instead of the CUDA/Numba ones.
 """
+import os
+
 import numpy as np
 
 from warp_drive_amd.utils import spaces
@@ -194,6 +196,9 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         fm.initialize_functions([name])
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         epb, block, grid = self._geometry()
+        if rollout and self._specialised_rollout_shape():
+            # the specialised rollout kernel runs blocks of ONE wavefront (12 replicas) at every batch size
+            epb, block, grid = 12, (64, 1, 1), ((int(dm.meta_info("n_envs")) + 11) // 12, 1)
         args = list(self.cuda_step_function_feed(_STEP_ARGS)) + [
             sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0], reset_args[1],
             _stream_tag("tick")]
@@ -219,8 +224,35 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
             else:
                 cache_dwords = 0
             args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"], np.int32(cache_dwords)]
+            special = self._specialised_rollout(name, block, cache_dwords)
+            if special is not None:
+                # the kernel specialised for this shape (csrc/kernels/tag_gridworld_n5.hip, its own code object):
+                # same arguments + the device address of the action table the host uploads into the main code object
+                fm.initialize_functions([special])
+                lds5 = 4 * (epb * N * F + epb * cache_dwords + 64 + int(self.episode_length) + 1)
+                return (fm.get_function(special), args + [fm.global_address("kIndexToActionArr")], block, grid,
+                        (lds5 + 15) // 16 * 16)
             return fm.get_function(name), args, block, grid, lds
         return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
+
+    SPECIALISED_ROLLOUT = os.environ.get("WD_GW_ROLLOUT_N5", "1") != "0"  # False: always the general rollout kernel
+
+    def _specialised_rollout_shape(self):
+        """the shape `HipTagGridWorldRollout_N5` is written for: 5 agents, full observations, and the registered reset
+        arrays exactly the positions and the observations (the kernel restores those, and only those, in registers /
+        LDS and writes them out after the last tick)"""
+        dm, fm = self.cuda_data_manager, self.cuda_function_manager
+        return (self.SPECIALISED_ROLLOUT and self.num_agents == 5 and bool(self.use_full_observation)
+                and int(self.grid_length) <= 63 and int(self.episode_length) <= 4095
+                and sorted(dm.reset_data_list) == sorted([_LOC_X, _LOC_Y, _OBSERVATIONS])
+                and fm.has_function("HipTagGridWorldRollout_N5"))
+
+    def _specialised_rollout(self, name, block, cache_dwords):
+        """`HipTagGridWorldRollout_N5` when the launch has its shape, blocks of one wavefront and the restore rows
+        cached in LDS, else None: the general kernel."""
+        ok = (name == "HipTagGridWorldRollout" and int(block[0]) == 64 and cache_dwords > 0
+              and self._specialised_rollout_shape())
+        return name + "_N5" if ok else None
 
     def step(self, actions=None):
         self.timestep += 1

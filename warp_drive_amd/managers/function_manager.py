@@ -16,6 +16,7 @@ in-tree code object when its sources are newer, rank 0 only, with the same
 multiprocessing-Event hand-shake as the reference (:170-181,:227-228).
 """
 import logging
+import os
 import time
 import zlib
 from typing import Optional
@@ -259,6 +260,7 @@ class HIPFunctionManager(CUDAFunctionManager):
         self._device_id = int(process_id if device_id is None else device_id)
         drv.ensure_init(self._device_id)
         self._module = None
+        self._extra_modules = None  # code objects of drv.EXTRA_HSACO_PATHS, loaded when a function is first asked for
         self._functions = {}
         self._function_names = []
 
@@ -310,11 +312,26 @@ class HIPFunctionManager(CUDAFunctionManager):
         for fname in func_names or []:
             if fname in self._functions:
                 continue
-            self._functions[fname] = self._module.get_function(fname)
+            module = self._module
+            if not module.has_function(fname):  # a shape-specialised kernel of one of the extra code objects?
+                module = next((m for m in self._load_extra_modules() if m.has_function(fname)), self._module)
+            self._functions[fname] = module.get_function(fname)  # (raises with the name when nobody has it)
             self._function_names.append(fname)
 
+    def _load_extra_modules(self):
+        if self._extra_modules is None:
+            self._extra_modules = [drv.Module(p) for p in drv.EXTRA_HSACO_PATHS if os.path.exists(p)]
+        return self._extra_modules
+
     def has_function(self, fname):
-        return self._module is not None and self._module.has_function(fname)
+        if self._module is None:
+            return False
+        return self._module.has_function(fname) or any(m.has_function(fname) for m in self._load_extra_modules())
+
+    def global_address(self, name):
+        """device address of a __device__ / __constant__ symbol of the MAIN code object (for kernels of the extra
+        code objects that read a table the host uploads there)"""
+        return self._module.get_global(name)[0]
 
     def initialize_shared_constants(self, data_manager, constant_names: list):
         """Upload DataManager shared constants into __constant__ symbols (:363-379)."""

@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libwdhip.so")
 HSACO_PATH = os.environ.get("WD_HSACO", os.path.join(_CSRC, "wd_kernels.hsaco"))  # override: experiments only
+# shape-specialised kernels in their own code objects (warp_drive_amd/build.py EXTRA_UNITS), loaded on demand
+EXTRA_HSACO_PATHS = (os.path.join(_CSRC, "wd_kernels_gw5.hsaco"),)
 
 # every symbol include/wd_hip.h declares (tests assert the library exports them all)
 C_ABI_SYMBOLS = (
