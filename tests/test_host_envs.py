@@ -96,3 +96,37 @@ def test_tag_continuous_lds_fits_a_workgroup_up_to_1024_agents():
     assert lds(100, 20) <= 20480              # eight blocks per CU at the BASELINE shape
     assert lds(500, 20) <= 80 * 1024          # two blocks per CU at ~510 agents (one slab: 42 KB, not 85)
     assert lds(1000, 20) <= 160 * 1024 < lds(1000, 40)
+
+
+def test_observation_placeholders_one_reset_equals_a_reset_per_replica(monkeypatch):
+    """envs whose reset draws nothing (RESET_IS_DETERMINISTIC) are reset once on the host and the observation copied
+    to every replica: the arrays must be what the reference's reset-per-replica loop produces (data_loader.py:348)"""
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.envs.tag_gridworld import TagGridWorld
+    from warp_drive_amd.training import data_loader
+
+    class Wrapper:
+        def __init__(self, env, E):
+            self.env, self.n_envs, self.resets = env, E, 0
+
+        def obs_at_reset(self):
+            self.resets += 1
+            return self.env.reset()
+
+    feeds = []
+    monkeypatch.setattr(data_loader, "_push", lambda w, feed: feeds.append(feed))
+    for env in (TagContinuous(num_taggers=2, num_runners=9, num_other_agents_observed=4, seed=3),
+                TagGridWorld(num_taggers=4, grid_length=7, episode_length=9, seed=5, use_full_observation=True)):
+        ids = sorted(env.reset().keys())
+        w = Wrapper(env, 6)
+        data_loader._observation_placeholders(w, ids, len(ids))
+        assert w.resets == 1
+        env.RESET_IS_DETERMINISTIC = False  # (instance attribute: the reference's way)
+        w = Wrapper(env, 6)
+        data_loader._observation_placeholders(w, ids, len(ids))
+        assert w.resets == 6
+        one, per_replica = feeds[-2], feeds[-1]
+        assert list(one.keys()) == list(per_replica.keys())
+        for key in one:
+            a, b = np.asarray(one[key]["data"]), np.asarray(per_replica[key]["data"])
+            assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes(), key

@@ -36,6 +36,7 @@ f32 = np.float32
 
 class TagContinuous(CUDAEnvironmentContext):
     name = "TagContinuous"
+    RESET_IS_DETERMINISTIC = True  # reset() restarts from the positions drawn in the constructor: no random draw
 
     def __init__(self, num_taggers=1, num_runners=10, grid_length=10.0, episode_length=100,
                  starting_location_x=None, starting_location_y=None, starting_directions=None, seed=None,

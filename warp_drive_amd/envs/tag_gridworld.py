@@ -26,6 +26,7 @@ class TagGridWorld:
     """CPU environment (one replica)."""
 
     name = "TagGridWorld"
+    RESET_IS_DETERMINISTIC = True  # reset() restarts from the constructor's starting locations: no random draw
 
     def __init__(self, num_taggers=10, grid_length=10, episode_length=100, starting_location_x=None,
                  starting_location_y=None, seed=None, wall_hit_penalty=0.1, tag_reward_for_tagger=10.0,
@@ -282,6 +283,7 @@ class CUDATagGridWorldWithResetPool(_DeviceStepMixin, TagGridWorld):
     """Device version whose replicas restart from a random member of a pool (reference :383-475)."""
 
     POOL_SIZE = 5  # hard-coded in the reference too (:429)
+    RESET_IS_DETERMINISTIC = False  # (kept per-replica: the observation placeholders are built the reference's way)
 
     def __init__(self, *args, **kwargs):
         TagGridWorld.__init__(self, *args, **kwargs)
