@@ -332,3 +332,54 @@ SETS["occupancy"] = {"base": [], "lds16k": [(TC, "#define WD_TC_STAGE_TARGET 540
 
 # ---- round 4: the prefiltered search of replicas of more than 128 agents on / off ("nopre" = the full chain, as before)
 SETS["prefilter_big"] = {"base": [], "pop2": [(TC, "constexpr int POPS = (IDB == 10) ? 1 : 2;", "constexpr int POPS = 2;")], "nopre": [(TC, "constexpr bool PRE = (IDB != 7) && (KMAX <= 12);", "constexpr bool PRE = false;")]}
+
+
+# ---- round 4 (prepared, NOT measured: the GPU budget of the round was spent): the next steps for the prefiltered search of big
+# replicas that experiments/offline/knn_prefilter_big_sim.py prices.  "rank_radius": the radius from the (K + 1)-th SMALLEST
+# current squared distance to the remembered agents (x 1.1; it provably holds K agents) instead of 1.15 x (K + 3) / n x the
+# largest, falling back to that heuristic when fewer than K + 1 remembered agents are still in the game -- 134 -> ~100 chain
+# insertions per wavefront at 1005 agents in the replay.  Build + bench: variants.py build / bench prefilter_next --num-runners 1000
+_RANK_RADIUS = [
+    (TC, """  float far = 0.0f;
+  unsigned n = 0u;
+#define WD_TC_PREV_DIST(k)                                                                                  \\
+  if (k < M) {                                                                                              \\
+    const float dx = xi - p##k.x, dy = yi - p##k.y;                                                         \\
+    const float d2 = dx * dx + dy * dy;                                                                     \\
+    far = fmaxf(far, d2); /* (maxnum: a NaN operand is ignored) */                                          \\
+    asm("v_cmp_o_f32 vcc, %1, %1\\n\\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(d2) : "vcc");       \\
+  }""",
+     """  float far = 0.0f;
+  unsigned n = 0u;
+  float dd[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) dd[k] = __builtin_inff();
+#define WD_TC_PREV_DIST(k)                                                                                  \\
+  if (k < M) {                                                                                              \\
+    const float dx = xi - p##k.x, dy = yi - p##k.y;                                                         \\
+    const float d2 = dx * dx + dy * dy;                                                                     \\
+    far = fmaxf(far, d2); /* (maxnum: a NaN operand is ignored) */                                          \\
+    asm("v_cmp_o_f32 vcc, %1, %1\\n\\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(d2) : "vcc");       \\
+    dd[k] = (d2 == d2) ? d2 : __builtin_inff();                                                             \\
+  }"""),
+    (TC, """  const float T = far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
+  return (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;""",
+     """  // the (K + 1)-th smallest of the M current distances (rank by counting, ties by slot: 78 compares once per tick)
+  int cnt[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) cnt[k] = 0;
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = i + 1; j < M; ++j) {
+      const int c = (dd[j] < dd[i]) ? 1 : 0;
+      cnt[i] += c;
+      cnt[j] += 1 - c;
+    }
+  float kth = 0.0f;
+#pragma unroll
+  for (int i = 0; i < M; ++i) kth = (cnt[i] == K) ? dd[i] : kth;
+  const float T = far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
+  return (n >= (unsigned)(K + 1)) ? __float_as_uint(kth * 1.1f) : (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;"""),
+]
+SETS["prefilter_next"] = {"base": [], "rank_radius": _RANK_RADIUS}
