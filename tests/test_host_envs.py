@@ -130,3 +130,46 @@ def test_observation_placeholders_one_reset_equals_a_reset_per_replica(monkeypat
         for key in one:
             a, b = np.asarray(one[key]["data"]), np.asarray(per_replica[key]["data"])
             assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes(), key
+
+
+def test_gridworld_rollout_kernel_choice():
+    """`HipTagGridWorldRollout_N5` serves exactly the shape it is written for (5 agents, full observations, the
+    positions and the observations as the only registered reset arrays, the kernel present); anything else -- and
+    `SPECIALISED_ROLLOUT = False` -- keeps the general kernel (envs/tag_gridworld.py::_specialised_rollout_shape)"""
+    from warp_drive_amd.envs.tag_gridworld import CUDATagGridWorld
+
+    class FakeDM:
+        reset_data_list = ["loc_x", "loc_y", "observations"]
+
+    class FakeFM:
+        present = True
+
+        def has_function(self, name):
+            return self.present and name == "HipTagGridWorldRollout_N5"
+
+    def env(**kw):
+        cfg = dict(num_taggers=4, grid_length=10, episode_length=100, seed=1, use_full_observation=True)
+        cfg.update(kw)
+        e = CUDATagGridWorld(**cfg)
+        e.cuda_data_manager, e.cuda_function_manager = FakeDM(), FakeFM()
+        return e
+
+    e = env()
+    assert e._specialised_rollout_shape()
+    assert e._specialised_rollout("HipTagGridWorldRollout", (64, 1, 1), 115) == "HipTagGridWorldRollout_N5"
+    assert e._specialised_rollout("HipTagGridWorldRollout", (256, 1, 1), 115) is None      # blocks of several wavefronts
+    assert e._specialised_rollout("HipTagGridWorldRollout", (64, 1, 1), 0) is None         # no room for the restore cache
+    assert e._specialised_rollout("HipTagGridWorldTick", (64, 1, 1), 115) is None
+    assert not env(num_taggers=5)._specialised_rollout_shape()                             # 6 agents
+    assert not env(use_full_observation=False)._specialised_rollout_shape()
+    assert not env(grid_length=64)._specialised_rollout_shape()                            # cells beyond the quotient table
+    assert not env(episode_length=5000)._specialised_rollout_shape()
+    e = env()
+    e.cuda_data_manager.reset_data_list = ["loc_x", "loc_y", "observations", "something_else"]
+    assert not e._specialised_rollout_shape()   # an array the kernel would not restore
+    e = env()
+    e.cuda_function_manager.present = False
+    assert not e._specialised_rollout_shape()   # the extra code object is not there
+    e = env()
+    e.SPECIALISED_ROLLOUT = False
+    assert not e._specialised_rollout_shape()
