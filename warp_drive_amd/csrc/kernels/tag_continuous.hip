@@ -916,6 +916,7 @@ template <int KMAX>
 __device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int pad_id, float xi, float yi, uint4 pa, uint4 pb,
                                                    int K) {
   constexpr int M = KMAX + 3;
+  static_assert(M <= 15, "the remembered neighbours are sixteen 16-bit ids per agent, K + 3 of them in use");
   float2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14;
 #define WD_TC_PREV_POS(k, vec, word) \
   if (k < M) p##k = xy_by_id[min((vec.word >> (16 * (k & 1))) & 0xffffu, (unsigned)pad_id)]  // out of the game / none / garbage: NaN
