@@ -14,7 +14,8 @@
 // Two implementations share the move / reward code:
 //
 //   tc_fast_impl<KMAX>   N <= 1024 agents per replica, K <= KMAX <= 32 observed neighbours (K <= 16 beyond 512 agents)
-//     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k>, ..._K<k>_N1024 beyond 512 agents).
+//     (the BASELINE shape: N = 105, K = 10; entry points Hip...Step_K<k> / Tick_K<k> up to 128 agents, ..._K<k>_N512 up to
+//     512, ..._K<k>_N1024 beyond).
 //     block = `epb` whole replicas (105 agents -> 1 replica on 128 threads), thread = agent.
 //       fetch    every global LOAD of the tick is issued first (state, step rewards, time step, action
 //                tables; the memory counters return in order, so a load issued later would wait for all
@@ -38,7 +39,10 @@
 //                ~1e-7 of the agents repeat the search with the two-pass one (tc_knn_registers: exact K-th
 //                distance, compare-mask pass, id-ordered peeling) or, beyond 128 candidates, have the whole
 //                wavefront resolve the zone around the cut (tc_zone_resolve).  While at most 64 agents are in
-//                the game both wavefronts of a block chain half of the candidates each (tc_merge_sorted);
+//                the game both wavefronts of a block chain half of the candidates each (tc_merge_sorted).  Replicas
+//                of more than 128 agents search inside a radius derived from the previous tick's neighbours while at
+//                least 200 agents are in the game (tc_chain_prefiltered: one compare per candidate, the chain over
+//                the candidates inside the radius only, the radius checked afterwards);
 //       ids out  packed indices -> agent ids through an LDS table; 16-bit block-local ids per agent
 //                row in LDS (entry k -> slot k; out-of-order lanes rewrite their rows by rank); one
 //                block barrier; nearest_neighbor_ids rows are converted from them and stored;
