@@ -383,3 +383,15 @@ _RANK_RADIUS = [
   return (n >= (unsigned)(K + 1)) ? __float_as_uint(kth * 1.1f) : (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;"""),
 ]
 SETS["prefilter_next"] = {"base": [], "rank_radius": _RANK_RADIUS}
+
+
+# ---- round 4 (prepared, not measured): how much of the headline tick is index arithmetic on runtime sizes?  The sizes of
+# the BASELINE shape as compile-time constants in EVERY entry (bench the headline shape only: other shapes break) -- the upper
+# bound of what `_N105`-style specialised entries could give (the TagGridWorld rollout lost half its instructions this way)
+SETS["constfold"] = {"base": [], "n105": [
+    (TC, "a.done = done_arr; a.timestep = env_timestep_arr; a.N = kNumAgents; a.T = kEpisodeLength;",
+     "a.done = done_arr; a.timestep = env_timestep_arr; a.N = 105; a.T = 500;"),
+    (TC, "a.turn_actions = turn_actions_arr; a.max_speed = kMaxSpeed; a.K = kNumOtherAgentsObserved;",
+     "a.turn_actions = turn_actions_arr; a.max_speed = kMaxSpeed; a.K = 10;"),
+    (TC, "tc_smem, kNumAccelerationActions, kNumTurnActions)", "tc_smem, 20, 20)"),
+]}
