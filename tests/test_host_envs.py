@@ -173,3 +173,29 @@ def test_gridworld_rollout_kernel_choice():
     e = env()
     e.SPECIALISED_ROLLOUT = False
     assert not e._specialised_rollout_shape()
+
+
+@pytest.mark.parametrize("hidden", [32, 64])
+def test_prepared_gridworld_policy_packing_matches_the_framework_model(hidden):
+    """experiments/gw5_policy (the live-policy TagGridWorld rollout, prepared for the next round): the packed layout
+    and the float32 restatement of the in-kernel forward reproduce training.models.FullyConnected to rounding"""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "gw5_policy"))
+    import policy_oracle as po
+    from warp_drive_amd.training.models import FullyConnected
+
+    torch.manual_seed(hidden)
+    model = FullyConnected(21, [5], [hidden, hidden])
+    packed = po.pack_model(model)
+    assert packed.size == po.policy_floats(hidden) and packed.size % 4 == 0
+    x = np.random.RandomState(1).rand(40, 21).astype(np.float32)
+    p = po.probabilities(packed, hidden, x)
+    with torch.no_grad():
+        q = model.forward_inference(torch.from_numpy(x))[0]
+    q = (q[0] if isinstance(q, (list, tuple)) else q).numpy()
+    assert np.abs(p - q).max() < 1e-6
+    c = po.running_sums(p)
+    assert (np.diff(c, axis=1) >= 0).all() and np.abs(c[:, -1] - 1).max() < 1e-6
