@@ -20,7 +20,8 @@ What is recorded
                           test_tag_continuous.py:15-80 and for the 5x100 K=10
                           benchmark shape, reference tag_continuous.py:796-887
                           (bench5x100_ep: the same shape with 15-tick episodes, so
-                          episode ends and restarts are recorded from the reference too).
+                          episode ends and restarts are recorded from the reference too;
+                          big5x250: a 255-agent replica, the sizes the `_N512` entries serve).
   * loss_fixtures.npz -- the reference's A2C / PPO `compute_loss_and_metrics`
                           (training/algorithms/policygradient/a2c.py:40-194, ppo.py:42-228) on
                           seeded random batches: inputs, loss, every logged metric and the
@@ -509,7 +510,26 @@ def main():
     gen_tag_continuous_traj("bench5x100_full", dict(bench_cfg, use_full_observation=True), 1, 3, 3100)
     # the bench shape through episode ends and restarts (15-tick episodes, 3 episodes)
     gen_tag_continuous_traj("bench5x100_ep", dict(bench_cfg, episode_length=15), 2, 47, 3200)
+    gen_big_replica()
+
+
+def gen_big_replica():
+    """a replica of MORE THAN 128 AGENTS from the reference itself (255 agents: three wavefronts of searchers, 9 id
+    bits in the search keys, the prefiltered neighbour search), through an episode end and restart (8-tick episodes)"""
+    bench_cfg = dict(num_taggers=5, num_runners=250, grid_length=20.0, episode_length=8,
+                     max_acceleration=0.1, min_acceleration=-0.1, max_turn=2.356, min_turn=-2.356,
+                     num_acceleration_levels=20, num_turn_levels=20, skill_level_runner=1.0,
+                     skill_level_tagger=1.0, max_speed=1.0, seed=274880,
+                     use_full_observation=False, num_other_agents_observed=10,
+                     tagging_distance=0.02, tag_reward_for_tagger=10.0,
+                     tag_penalty_for_runner=-10.0, step_penalty_for_tagger=-0.0,
+                     step_reward_for_runner=0.0, edge_hit_penalty=-0.0,
+                     end_of_game_reward_for_runner=1.0, runner_exits_game_after_tagged=True)
+    gen_tag_continuous_traj("big5x250", bench_cfg, 1, 13, 3300)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":  # only the fixture added in round 4
+        gen_big_replica()
+    else:
+        main()

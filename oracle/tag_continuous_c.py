@@ -60,7 +60,9 @@ class TagContinuousCOracle:
             setattr(self, k, np.ascontiguousarray(np.repeat(v, E, axis=0)))
         self.rewards = np.zeros((E, self.N), f32)
         self.obs_at_reset = np.ascontiguousarray(one.obs_at_reset.astype(f32)[0])
-        self.obs = np.ascontiguousarray(np.broadcast_to(self.obs_at_reset, (E,) + self.obs_at_reset.shape))
+        # (a fresh writable array: for one replica the broadcast is already contiguous and ascontiguousarray would
+        # hand back the read-only VIEW of obs_at_reset, which the C step then writes through)
+        self.obs = np.array(np.broadcast_to(self.obs_at_reset, (E,) + self.obs_at_reset.shape), dtype=np.float32, order="C")
         return self.obs
 
     def step(self, actions):

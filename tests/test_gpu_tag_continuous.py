@@ -117,7 +117,8 @@ def _run_lockstep(cfg, E, ticks, seed, stats=None):
     return stats
 
 
-TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep"]
+TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep",
+           "big5x250"]  # big5x250: a 255-agent replica recorded from the reference (the `_N512` entries, prefiltered search)
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)

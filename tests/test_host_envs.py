@@ -39,7 +39,7 @@ def test_gridworld_cpu_backend(golden_dir, tag):
                 e.reset()
 
 
-@pytest.mark.parametrize("tag", ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_ep"])
+@pytest.mark.parametrize("tag", ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_ep", "big5x250"])
 def test_tag_continuous_cpu_backend(golden_dir, tag):
     d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
     E = d["actions"].shape[1]

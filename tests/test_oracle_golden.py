@@ -62,7 +62,7 @@ def test_gridworld_trajectory(golden_dir, tag):
 
 
 # --------------------------------------------------------------- TagContinuous
-TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep"]
+TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep", "big5x250"]
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)
@@ -141,7 +141,7 @@ def test_powf2_is_numpy_scalar_power():
     np.testing.assert_array_equal(out, ref)
 
 
-@pytest.mark.parametrize("tag", ["test2", "test3", "tagheavy", "bench5x100", "bench5x100_full"])
+@pytest.mark.parametrize("tag", ["test2", "test3", "tagheavy", "bench5x100", "bench5x100_full", "big5x250"])
 def test_c_step_matches_reference(golden_dir, tag):
     """The C restatement (bench.py's cpu_baseline 'port') replays the reference bit-exactly."""
     d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
@@ -187,7 +187,7 @@ def test_c_step_matches_reference(golden_dir, tag):
             st[k][m] = v
 
 
-@pytest.mark.parametrize("tag", ["test3", "tagheavy", "bench5x100"])
+@pytest.mark.parametrize("tag", ["test3", "tagheavy", "bench5x100", "big5x250"])
 def test_c_oracle_neighbour_ids_match_the_numpy_oracle(golden_dir, tag):
     """`TagContinuousCOracle.nearest_ids` (the checker of the device's nearest_neighbor_ids output in the
     full-size fused-tick tests) against the numpy oracle's k_nearest_neighbors restatement
