@@ -208,7 +208,7 @@ def gen_gridworld_traj(tag, cfg, num_envs, num_ticks, action_seed):
 _TC_STATE = ("loc_x", "loc_y", "speed", "direction", "acceleration")
 
 
-def gen_tag_continuous_traj(tag, cfg, num_envs, num_ticks, action_seed):
+def gen_tag_continuous_traj(tag, cfg, num_envs, num_ticks, action_seed, obs_dtype=None):
     envs = [EnvWrapper(env_obj=TagContinuous(**cfg), env_backend="cpu") for _ in range(num_envs)]
     e0 = envs[0].env
     n = e0.num_agents
@@ -251,6 +251,8 @@ def gen_tag_continuous_traj(tag, cfg, num_envs, num_ticks, action_seed):
     out = {k: np.stack(v) for k, v in rec.items()}
     out["obs"] = out["obs"]  # float64 as returned by the reference (numpy 2 promotion)
     out["obs_at_reset"] = obs0
+    if obs_dtype is not None:
+        out["obs"], out["obs_at_reset"] = out["obs"].astype(obs_dtype), obs0.astype(obs_dtype)
     out["agent_types"] = np.array([e0.agent_type[a] for a in range(n)], dtype=np.int32)
     out["start_x"] = np.asarray(e0.starting_location_x, dtype=np.float64)
     out["start_y"] = np.asarray(e0.starting_location_y, dtype=np.float64)
@@ -526,6 +528,9 @@ def gen_big_replica():
                      step_reward_for_runner=0.0, edge_hit_penalty=-0.0,
                      end_of_game_reward_for_runner=1.0, runner_exits_game_after_tagged=True)
     gen_tag_continuous_traj("big5x250", bench_cfg, 1, 13, 3300)
+    # ... and of more than 512 (1005 agents: sixteen wavefronts, 10 id bits: the `_N1024` entries); the observations are
+    # stored as float32 (the cast every comparison applies to the reference's float64 anyway) to keep the file small
+    gen_tag_continuous_traj("big5x1000", dict(bench_cfg, num_runners=1000, episode_length=3), 1, 5, 3400, obs_dtype=np.float32)
 
 
 if __name__ == "__main__":

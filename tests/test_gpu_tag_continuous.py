@@ -118,7 +118,8 @@ def _run_lockstep(cfg, E, ticks, seed, stats=None):
 
 
 TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep",
-           "big5x250"]  # big5x250: a 255-agent replica recorded from the reference (the `_N512` entries, prefiltered search)
+           "big5x250", "big5x1000"]  # replicas of 255 / 1005 agents recorded from the reference (the `_N512` / `_N1024`
+                                     # entries, prefiltered search)
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)

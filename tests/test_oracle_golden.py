@@ -62,7 +62,7 @@ def test_gridworld_trajectory(golden_dir, tag):
 
 
 # --------------------------------------------------------------- TagContinuous
-TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep", "big5x250"]
+TC_TAGS = ["test1", "test2", "test3", "test4", "tagheavy", "bench5x100", "bench5x100_full", "bench5x100_ep", "big5x250", "big5x1000"]
 
 
 @pytest.mark.parametrize("tag", TC_TAGS)
@@ -79,7 +79,10 @@ def test_tag_continuous_trajectory(golden_dir, tag):
     np.testing.assert_array_equal(orc.skill_levels, d["skill_levels"])
     np.testing.assert_array_equal(orc.step_rewards, d["step_rewards"])
     assert orc.distance_margin_for_reward == d["distance_margin_for_reward"]
-    np.testing.assert_array_equal(orc.obs, d["obs_at_reset"])
+    # (the 1005-agent fixture stores the observations as float32 -- the cast every device comparison applies to the
+    # reference's float64 rows anyway -- to stay small: compare in the fixture's dtype)
+    as_stored = (lambda a: a) if d["obs"].dtype == np.float64 else (lambda a: a.astype(d["obs"].dtype))
+    np.testing.assert_array_equal(as_stored(orc.obs), d["obs_at_reset"])
     for t in range(d["actions"].shape[0]):
         obs, rew, done = orc.step(d["actions"][t])
         for k, attr in (("loc_x", "loc_x"), ("loc_y", "loc_y"), ("speed", "speed"),
@@ -89,7 +92,7 @@ def test_tag_continuous_trajectory(golden_dir, tag):
             np.testing.assert_array_equal(getattr(orc, attr), d[k][t], err_msg=f"{k} t={t}")
         np.testing.assert_array_equal(done.astype(bool), d["done"][t], err_msg=f"done t={t}")
         np.testing.assert_array_equal(rew.astype(np.float64), d["rewards"][t], err_msg=f"rew t={t}")
-        np.testing.assert_array_equal(obs, d["obs"][t], err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(as_stored(obs), d["obs"][t], err_msg=f"obs t={t}")
         orc.reset_done_envs()
 
 
@@ -141,7 +144,7 @@ def test_powf2_is_numpy_scalar_power():
     np.testing.assert_array_equal(out, ref)
 
 
-@pytest.mark.parametrize("tag", ["test2", "test3", "tagheavy", "bench5x100", "bench5x100_full", "big5x250"])
+@pytest.mark.parametrize("tag", ["test2", "test3", "tagheavy", "bench5x100", "bench5x100_full", "big5x250", "big5x1000"])
 def test_c_step_matches_reference(golden_dir, tag):
     """The C restatement (bench.py's cpu_baseline 'port') replays the reference bit-exactly."""
     d, cfg = _load(golden_dir, f"tc_traj_{tag}.npz")
@@ -187,7 +190,7 @@ def test_c_step_matches_reference(golden_dir, tag):
             st[k][m] = v
 
 
-@pytest.mark.parametrize("tag", ["test3", "tagheavy", "bench5x100", "big5x250"])
+@pytest.mark.parametrize("tag", ["test3", "tagheavy", "bench5x100", "big5x250", "big5x1000"])
 def test_c_oracle_neighbour_ids_match_the_numpy_oracle(golden_dir, tag):
     """`TagContinuousCOracle.nearest_ids` (the checker of the device's nearest_neighbor_ids output in the
     full-size fused-tick tests) against the numpy oracle's k_nearest_neighbors restatement
