@@ -7,7 +7,10 @@
 // wavefront's dependent chain (~530 instructions at ~5 cycles each, two block barriers, ~20 dependent LDS round
 // trips: 2.14 us per tick).  What a block of one wavefront does not need:
 //   * barriers and LDS vote flags: LDS operations of ONE wavefront execute in issue order, so a lane's read sees any
-//     earlier write of another lane; "did any replica finish" is a ballot;
+//     earlier write of another lane; "did any replica finish" is a ballot.  (The wavefront-scope fence at the top
+//     of the tick loop is the language-level statement of the same thing; it compiles to nothing here -- the
+//     instruction stream is identical with and without it, checked by diffing the assembly -- because every access
+//     goes through the same image pointer and already may alias the others);
 //   * positions in LDS for the tag check: the runner's cell reaches the replica's five lanes through one
 //     ds_bpermute, "some tagger stands on it" is a ballot + a shift;
 //   * the per-replica time step in LDS: every lane keeps its replica's in a register;
@@ -124,6 +127,7 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
     const int runner_lane = min(el * GW5_N + GW5_N - 1, 63);
 
     for (int k = 0; k < ticks; ++k) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tick's image writes / restores, before this tick's record reads
       // ---- record the observation of this tick (flat, coalesced; none of the record stores is tracked).  The usual
       // case -- the block's slice of the row is a whole number of 16-byte vectors on a 16-byte boundary -- reads its
       // (up to) five vectors per lane with all LDS reads in flight, then stores them; a loop of read / wait / store
