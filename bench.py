@@ -93,7 +93,7 @@ def valu_roofline(kernel, num_envs, full_obs, kernel_us):
     try:
         from warp_drive_amd.managers import hip_driver
 
-        sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
+        sha = hip_driver.code_object_sha256(kernel)
         rec = json.load(open(path))
         if (rec.get("hsaco_sha256") != sha or rec.get("kernel") != kernel or rec.get("num_envs") != num_envs
                 or bool(rec.get("full_obs")) != full_obs):
@@ -114,29 +114,62 @@ def valu_roofline(kernel, num_envs, full_obs, kernel_us):
         return None
 
 
+def _cpu_quota_cores():
+    """CPU bandwidth limit of this cgroup in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, target_seconds=12.0):
-    """The oracle's C restatement (oracle/csrc/wd_oracle.c) timed on this host's cores,
-    on a bounded sample of the same workload.  Reported, never the optimisation target."""
+    """The oracle's C restatement (oracle/csrc/wd_oracle.c) timed on this host's cores, on a bounded sample of the
+    same workload: once on ONE core and once on every core this process may run on (its affinity mask, capped by the
+    cgroup's CPU quota).  All ticks of a run happen inside one C call (replicas are independent: a thread takes chunks
+    of replicas through all their ticks, dynamic schedule, no per-tick Python or numpy work).  Reported, never the
+    optimisation target."""
     from oracle.tag_continuous_c import TagContinuousCOracle
 
-    cores = os.cpu_count() or 1
-    E = 32 * cores
-    orc = TagContinuousCOracle(E, n_threads=cores, **cfg)  # seeded start state (test infrastructure)
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    quota = _cpu_quota_cores()
+    cores = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
     rng = np.random.RandomState(0)
-    na, nt = len(orc.acceleration_actions), len(orc.turn_actions)
-    acts = np.stack([rng.randint(0, na, size=(E, orc.N)), rng.randint(0, nt, size=(E, orc.N))], 2).astype(np.int32)
-    orc.step(acts)  # warm-up + calibration
-    t0 = time.perf_counter()
-    orc.step(acts)
-    per_tick = max(time.perf_counter() - t0, 1e-6)
-    ticks = int(max(3, min(400, target_seconds / per_tick)))
-    t0 = time.perf_counter()
-    for _ in range(ticks):
-        orc.step(acts)
-    dt = time.perf_counter() - t0
-    return {"value": E * ticks / dt, "unit": "env_steps/s", "cores": cores, "kind": "port",
+
+    def run(E, threads, seconds):
+        orc = TagContinuousCOracle(E, n_threads=threads, **cfg)  # seeded start state (test infrastructure)
+        na, nt = len(orc.acceleration_actions), len(orc.turn_actions)
+        acts = np.stack([rng.randint(0, na, size=(E, orc.N)), rng.randint(0, nt, size=(E, orc.N))], 2).astype(np.int32)
+        t0 = time.perf_counter()
+        orc.run_ticks(acts, 2)  # warm-up (thread pool, page faults) + calibration
+        per_tick = max((time.perf_counter() - t0) / 2, 1e-6)
+        ticks = int(max(3, min(orc.T - 4, seconds / per_tick)))
+        t0 = time.perf_counter()
+        orc.run_ticks(acts, ticks)
+        dt = time.perf_counter() - t0
+        return E * ticks / dt, ticks, dt
+
+    single, ticks1, dt1 = run(16, 1, 0.25 * target_seconds)
+    # replicas per core sized so that a whole-episode run of the multi-core leg lasts about 0.75 x target
+    E = cores * max(16, int(0.75 * target_seconds * single / 496))
+    value, ticks, dt = (single, ticks1, dt1) if cores == 1 else run(E, cores, 0.75 * target_seconds)
+    return {"value": value, "unit": "env_steps/s", "cores": cores, "kind": "port",
+            "value_single_core": single, "cores_effective": value / single, "parallel_efficiency": value / single / cores,
+            "host": {"logical_cpus": logical, "affinity_cpus": affinity, "cgroup_cpu_quota": quota},
             "sample": f"{E} replicas x {ticks} ticks of the same TagContinuous 5x100 K=10 step from the start of an "
-                      f"episode, no resets (C restatement of the reference CPU step, OpenMP over replicas, {dt:.1f} s)"}
+                      f"episode, no resets (C restatement of the reference CPU step; {cores} OpenMP threads, chunks of 4 "
+                      f"replicas scheduled dynamically, {dt:.1f} s; single core: 16 replicas x {ticks1} ticks, {dt1:.1f} s). "
+                      "Orientation: the reference's own Python step() does ~49 env-steps/s per core (BASELINE.md section 3)"}
 
 
 def main():
@@ -378,7 +411,7 @@ def main():
             try:
                 from warp_drive_amd.managers import hip_driver
 
-                sha = hashlib.sha256(open(hip_driver.HSACO_PATH, "rb").read()).hexdigest()
+                sha = hip_driver.code_object_sha256(engine.step_kernel_name)
                 shape_recs = [r for r in json.load(open(pmc)).values()
                               if r.get("kernel") == engine.step_kernel_name and r.get("num_envs") == E
                               and r.get("full_obs") == bool(args.full_obs) and N == 105

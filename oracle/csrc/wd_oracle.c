@@ -102,6 +102,8 @@ typedef struct {
   int n_acc_actions, n_turn_actions;
 } wdo_tc_cfg;
 
+#define TC_SCRATCH_BYTES(N) (sizeof(double) * (N) * 2 + sizeof(float) * (N) * 4 + sizeof(int) * (N))
+
 /* One tick for envs [e0, e1).  All arrays are [E, N(,...)] row-major, float32 /
  * int32, the same layout the device uses.  obs is float32 [E, N, F]. */
 static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, float *loc_y,
@@ -110,18 +112,20 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
                           const float *turn_actions, const float *skill_levels, int *sig,
                           float *obs, const int *actions, float *rewards,
                           const float *step_rewards, int *num_runners, int *done,
-                          int *timestep, int *nearest_ids) {
+                          int *timestep, int *nearest_ids, void *scratch) {
   const int N = c->n_agents, K = c->num_other_agents_observed;
   const int F = c->use_full_observation ? 7 * (N - 1) + 1 : 7 * K + 1;
   const float two_pi = (float)(2 * M_PI); /* python float, weak-promoted to float32 */
   const float L = c->grid_length;
   const double diag = (double)L * sqrt(2.0);        /* :146  float32 * np.float64 -> f64 */
   const float sp_div = c->max_speed + 1e-10f;       /* :456  float32 + float32(eps)      */
-  double *nx = (double *)malloc(sizeof(double) * N * 2);
+  /* scratch: TC_SCRATCH_BYTES(N) supplied by the caller (once per thread), or allocated here */
+  void *own = scratch ? NULL : malloc(TC_SCRATCH_BYTES(N));
+  double *nx = (double *)(scratch ? scratch : own);
   double *ny = nx + N;
-  float *nf = (float *)malloc(sizeof(float) * N * 3); /* speed, acc, dir normalised (f32) */
-  float *cd = (float *)malloc(sizeof(float) * N);
-  int *cid = (int *)malloc(sizeof(int) * N);
+  float *nf = (float *)(nx + 2 * N); /* speed, acc, dir normalised (f32) */
+  float *cd = nf + 3 * N;
+  int *cid = (int *)(cd + N);
 
   for (int e = e0; e < e1; ++e) {
     float *x = loc_x + (size_t)e * N, *y = loc_y + (size_t)e * N;
@@ -248,7 +252,7 @@ static void tc_step_range(const wdo_tc_cfg *c, int e0, int e1, float *loc_x, flo
     num_runners[e] = nr;
     done[e] = (t >= c->episode_length) || (nr == 0); /* :880-883 */
   }
-  free(nx); free(nf); free(cd); free(cid);
+  free(own);
 }
 
 void wdo_tc_step_ids(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
@@ -261,7 +265,7 @@ void wdo_tc_step_ids(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *spe
   if (n_threads <= 1) {
     tc_step_range(c, 0, E, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen,
                   acc_actions, turn_actions, skill_levels, sig, obs, actions, rewards,
-                  step_rewards, num_runners, done, timestep, nearest_ids);
+                  step_rewards, num_runners, done, timestep, nearest_ids, NULL);
     return;
   }
 #ifdef _OPENMP
@@ -271,7 +275,38 @@ void wdo_tc_step_ids(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *spe
     const int e0 = (int)((long)E * b / n_threads), e1 = (int)((long)E * (b + 1) / n_threads);
     tc_step_range(c, e0, e1, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen,
                   acc_actions, turn_actions, skill_levels, sig, obs, actions, rewards,
-                  step_rewards, num_runners, done, timestep, nearest_ids);
+                  step_rewards, num_runners, done, timestep, nearest_ids, NULL);
+  }
+}
+
+/* cpu_baseline leg of bench.py: `n_ticks` ticks of every replica with the SAME actions each tick (no resets).
+ * Replicas are independent, so a thread takes a chunk of replicas through all its ticks (dynamic schedule over
+ * chunks, no barrier between ticks, scratch allocated once per thread). */
+void wdo_tc_run_ticks(const wdo_tc_cfg *c, float *loc_x, float *loc_y, float *speed,
+                      float *direction, float *acceleration, const int *agent_types,
+                      float *edge_pen, const float *acc_actions, const float *turn_actions,
+                      const float *skill_levels, int *sig, float *obs, const int *actions,
+                      float *rewards, const float *step_rewards, int *num_runners, int *done,
+                      int *timestep, int n_ticks, int chunk, int n_threads) {
+  const int E = c->n_envs;
+  if (chunk < 1) chunk = 1;
+  const int n_chunks = (E + chunk - 1) / chunk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  {
+    void *scratch = malloc(TC_SCRATCH_BYTES(c->n_agents));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int b = 0; b < n_chunks; ++b) {
+      const int e0 = b * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
+      for (int t = 0; t < n_ticks; ++t)
+        tc_step_range(c, e0, e1, loc_x, loc_y, speed, direction, acceleration, agent_types, edge_pen,
+                      acc_actions, turn_actions, skill_levels, sig, obs, actions, rewards,
+                      step_rewards, num_runners, done, timestep, NULL, scratch);
+    }
+    free(scratch);
   }
 }
 

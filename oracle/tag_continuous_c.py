@@ -83,6 +83,22 @@ class TagContinuousCOracle:
                                   P(self.num_runners), P(self.done), P(self.timestep), ids_p,
                                   ctypes.c_int(self.n_threads))
 
+    def run_ticks(self, actions, n_ticks, n_threads=None, chunk=4):
+        """`n_ticks` ticks of every replica with the SAME actions each tick, without resets and without the
+        neighbour-id output, entirely inside one C call (bench.py's cpu_baseline leg: no per-tick numpy work, replicas
+        handed to the threads in chunks of `chunk` with a dynamic schedule, scratch allocated once per thread)."""
+        assert self.timestep.max() + n_ticks <= self.T, "run_ticks does not reset: stay inside the episode"
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N, 2)
+        P = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+        self._lib.wdo_tc_run_ticks.restype = None
+        self._lib.wdo_tc_run_ticks(ctypes.byref(self._cfg), P(self.loc_x), P(self.loc_y), P(self.speed),
+                                   P(self.direction), P(self.acceleration), P(self.agent_types), P(self.edge_pen),
+                                   P(self.acceleration_actions), P(self.turn_actions), P(self.skill_levels),
+                                   P(self.sig), P(self.obs), P(a), P(self.rewards), P(self.step_rewards),
+                                   P(self.num_runners), P(self.done), P(self.timestep), ctypes.c_int(int(n_ticks)),
+                                   ctypes.c_int(int(chunk)),
+                                   ctypes.c_int(int(self.n_threads if n_threads is None else n_threads)))
+
     def reset_done_envs(self):
         """device-side reset semantics, as TagContinuousOracle.reset_done_envs"""
         m = self.done > 0

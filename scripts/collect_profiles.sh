@@ -43,7 +43,9 @@ from rocpd_summary import pmc_stats
 E = int(sys.argv[1])
 f = [r for r in pmc_stats(sys.argv[2], "FETCH_SIZE") if "Tick" in r["kernel"]][0]
 w = [r for r in pmc_stats(sys.argv[3], "WRITE_SIZE") if "Tick" in r["kernel"]][0]
-sha = hashlib.sha256(open(sys.argv[4] + "/warp_drive_amd/csrc/wd_kernels.hsaco", "rb").read()).hexdigest()
+sys.path.insert(0, sys.argv[4])
+from warp_drive_amd.managers import hip_driver
+sha = hip_driver.code_object_sha256(f["kernel"].replace(".kd", ""))  # the object that holds the kernel
 rec = {"kernel": f["kernel"], "num_envs": E, "full_obs": False, "hsaco_sha256": sha,
        "fetch_size_kb": f["avg"], "write_size_kb": w["avg"],
        "hbm_bytes_per_launch": (2 * f["avg"] + w["avg"]) * 1024,

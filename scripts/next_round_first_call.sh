@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/next
 mkdir -p $O
 # 1. the suite (incl. the two big-replica goldens added after the last GPU run of round 4)
-(timeout 200 python -m pytest tests -m gpu -q -x 2>&1 | tail -6) > $O/gpu_tests.txt
+(timeout 400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15) > $O/gpu_tests.txt
 # 2. the live-policy TagGridWorld rollout (experiments/gw5_policy/README.md): parity against the oracle + us per tick
 for h in 32 64; do (timeout 60 python experiments/gw5_policy/run_parity.py $h 1000 20 2>&1 | tail -4) > $O/gw5_policy_H$h.txt; done
 # 3. headline A/B: the BASELINE shape's sizes as compile-time constants (upper bound of what _N105-style entries give)
@@ -17,3 +17,4 @@ for h in 32 64; do (timeout 60 python experiments/gw5_policy/run_parity.py $h 10
 (timeout 150 python experiments/variants.py bench prefilter_next 2 --num-runners 500 --steps 500 --warmup 50 --no-spread 2>&1 | tail -3) > $O/ab_prefilter_next_505.txt
 (timeout 200 python experiments/variants.py bench prefilter_next 1 --num-runners 1000 --steps 100 --warmup 10 --no-spread 2>&1 | tail -3) > $O/ab_prefilter_next_1005.txt
 tail -n +1 $O/*.txt
+(timeout 120 python bench.py 2>&1 | tail -1) > $O/bench_default.txt; tail -n +1 $O/bench_default.txt

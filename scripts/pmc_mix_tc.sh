@@ -38,7 +38,9 @@ for line in open(out):
     m = re.match(r"(\S+)\s+avg=(\S+) kernel=(\S+)", line)
     if m:
         c[m.group(1)] = float(m.group(2)); kernel = m.group(3).replace('.kd', '')
-sha = hashlib.sha256(open(R + "/warp_drive_amd/csrc/wd_kernels.hsaco", "rb").read()).hexdigest()
+sys.path.insert(0, R)
+from warp_drive_amd.managers import hip_driver
+sha = hip_driver.code_object_sha256(kernel)  # the object that holds the kernel
 rec = {"kernel": kernel, "num_envs": E, "full_obs": False, "hsaco_sha256": sha, "counters_per_launch": c,
        "note": "rocprofv3 --pmc passes over one whole 500-tick episode each (scripts/pmc_mix_tc.sh); SQ_WAVE_CYCLES / "
                "SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}

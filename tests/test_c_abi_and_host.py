@@ -50,25 +50,38 @@ def test_header_is_plain_c_and_binds_from_c(built, tmp_path):
 
 
 def test_code_object_has_all_kernels(built):
+    """every kernel the host asks for by name is in the manifest, in the code object the manifest names, built for
+    gfx950; the main object holds the core services and the small envs, nothing test-only"""
+    from warp_drive_amd import build as wd_build
     from warp_drive_amd.managers.function_manager import DEFAULT_FUNCTION_NAMES
 
-    blob = open(built.HSACO_PATH, "rb").read()
-    wanted = list(DEFAULT_FUNCTION_NAMES) + ["HipTagGridWorldStep", "HipTagContinuousStep",
-                                             "HipTagContinuousStep_K10", "HipClassicControlCartPoleEnvStep",
-                                             "testkernel", "kIndexToActionArr", "wd_test_math", "HipTagContinuousTick_K10",
-                                             "HipTagContinuousTick", "HipTagGridWorldTick",
-                                             "HipClassicControlCartPoleEnvTick", "HipTagGridWorldRollout",
-                                             "HipTagContinuousStep_K10_N1024", "HipTagContinuousTick_K16_N1024",
-                                             "HipTagContinuousStep_K32_N512", "HipTagContinuousTick_K10_N512"]
-    for name in wanted:
-        assert name.encode() in blob, f"{name} is not in the code object"
-    assert b"gfx950" in blob
-    # shape-specialised kernels live in their own code objects (warp_drive_amd/build.py EXTRA_UNITS)
-    from warp_drive_amd.managers import hip_driver
-
-    for path, names in zip(hip_driver.EXTRA_HSACO_PATHS, (["HipTagGridWorldRollout_N5"],)):
-        extra = open(path, "rb").read()
-        assert all(n.encode() in extra for n in names) and b"gfx950" in extra, path
+    manifest = built.manifest()
+    main = os.path.basename(built.HSACO_PATH)
+    for name in list(DEFAULT_FUNCTION_NAMES) + ["HipTagGridWorldStep", "HipTagGridWorldTick", "HipTagGridWorldRollout",
+                                                "HipClassicControlCartPoleEnvStep", "HipClassicControlCartPoleEnvTick",
+                                                "testkernel"]:
+        assert manifest.get(name) == main, f"{name} is not in the main code object"
+    assert b"kIndexToActionArr" in open(built.HSACO_PATH, "rb").read()
+    wanted = {"HipTagContinuousStep": "wd_kernels_tc.hsaco", "HipTagContinuousTick": "wd_kernels_tc.hsaco",
+              "HipTagContinuousStep_K10": "wd_kernels_tc_k10.hsaco", "HipTagContinuousTick_K10": "wd_kernels_tc_k10.hsaco",
+              "HipTagContinuousTickA_K10": "wd_kernels_tc_k10.hsaco",
+              "HipTagContinuousTick_K10_N512": "wd_kernels_tc_k10.hsaco",
+              "HipTagContinuousStep_K10_N1024": "wd_kernels_tc_k10.hsaco",
+              "HipTagContinuousTick_K16_N1024": "wd_kernels_tc_k16.hsaco",
+              "HipTagContinuousStep_K32_N512": "wd_kernels_tc_k32.hsaco",
+              "HipTagContinuousTick_K10_N105A21": "wd_kernels_tc_k10_n105a21.hsaco",
+              "HipTagContinuousTickA_K10_N105A21": "wd_kernels_tc_k10_n105a21.hsaco",
+              "HipTagGridWorldRollout_N5": "wd_kernels_gw5.hsaco", "HipPolicyMlp_256x256_k3": "wd_kernels_mlp.hsaco",
+              "wd_test_math": "wd_kernels_test.hsaco", "wd_write_probe": "wd_kernels_test.hsaco"}
+    for name, obj in wanted.items():
+        assert manifest.get(name) == obj, (name, manifest.get(name))
+    for obj in set(manifest.values()):
+        assert obj in wd_build.UNITS
+        blob = open(built.code_object_path(obj), "rb").read()
+        assert b"gfx950" in blob
+        assert all(n.encode() + b".kd" in blob for n, o in manifest.items() if o == obj)
+    assert built.code_object_of("no_such_kernel") is None
+    assert set(built.extra_code_objects()) == {built.code_object_path(o) for o in wd_build.UNITS} - {built.HSACO_PATH}
 
 
 def test_no_silent_cpu_fallback(built):

@@ -151,7 +151,7 @@ def test_valu_roofline_from_a_pmc_file(tmp_path, monkeypatch):
 
     hsaco = tmp_path / "k.hsaco"
     hsaco.write_bytes(b"code object")
-    monkeypatch.setattr(hip_driver, "HSACO_PATH", str(hsaco))
+    monkeypatch.setattr(hip_driver, "code_object_of", lambda kernel: str(hsaco))  # the object that holds the kernel
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
     counters = {"SQ_WAVES": 4000.0, "SQ_INSTS_VALU": 4000.0 * 100, "SQ_INSTS_VALU_INT32": 4000.0 * 40,

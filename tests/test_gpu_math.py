@@ -12,7 +12,7 @@ def test_device_math_is_numpy_exact():
     from warp_drive_amd.managers import hip_driver as drv
 
     require_gpu()
-    mod = drv.Module(drv.HSACO_PATH)
+    mod = drv.Module(drv.code_object_of("wd_test_math"))  # the test-only code object
     fn = mod.get_function("wd_test_math")
     rng = np.random.RandomState(0)
     n = 1 << 20

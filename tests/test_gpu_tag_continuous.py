@@ -245,6 +245,7 @@ def test_bench_full_size_properties():
     (True, 2, 5, 60, 3, 4),        # full observations whose width is a multiple of four (16-byte stores)
     (False, 70, 3, 10, 3, 2),      # action table larger than its LDS copy (71 > 64 entries)
     (False, 6, 8, 400, 6, 3),      # more than 256 agents: the two heads are sampled one after the other from ONE slab
+    (False, 9, 5, 300, 6, 3),      # ... heads of unequal size, the first the larger (wavefronts' rows of the two heads overlap)
     (False, 20, 20, 1000, 10, 2),  # 1004 agents: sixteen wavefronts per replica, 10-bit search keys (`_N1024` entry)
 ])
 def test_fused_tick_kernel(full_obs, acc_levels, turn_levels, runners, K, E):
@@ -339,9 +340,26 @@ def _near_tie_rows_c(orc, bad_rows):
     return True
 
 
+HEADLINE_TICK = "HipTagContinuousTick_K10_N105A21"   # BASELINE shape, sizes folded (warp_drive_amd/build.py UNITS)
+
+
+@pytest.fixture
+def runtime_size_entries(monkeypatch):
+    """the `_K<k>` entries with runtime sizes instead of the shape-specialised one"""
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+
+    monkeypatch.setattr(TagContinuous, "SHAPE_ENTRIES", False)
+
+
+def test_runtime_size_entry_at_the_headline_shape(runtime_size_entries):
+    """`HipTagContinuousTick_K10` (runtime sizes; what every 65 .. 128-agent shape other than BASELINE's runs) at the
+    BASELINE shape, 300 replicas x 40 ticks of a 15-tick episode against the C oracle"""
+    _fused_ticks_vs_c_oracle(dict(BENCH_CFG, episode_length=15), 300, 40, 5, kernel="HipTagContinuousTick_K10")
+
+
 @pytest.mark.parametrize("full_obs,E,ticks", [(False, 2000, 44), (True, 64, 36)])
 def test_headline_fused_tick_full_size(full_obs, E, ticks):
-    """The (kernel, shape) pair bench.py reports: the fused HipTagContinuousTick_K10 at BASELINE
+    """The (kernel, shape) pair bench.py reports: the fused HipTagContinuousTick_K10_N105A21 at BASELINE
     configs[2] -- 5 taggers + 100 runners, 20 + 20 levels (21-way heads), K = 10, num_envs = 2000 --
     through RolloutEngine, EVERY replica compared with the C oracle on every tick: the sampled actions
     draw for draw (Philox restated on the host, random.cu:51-85), then state / observations / rewards /
@@ -374,7 +392,7 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     probs = [torch.from_numpy(p).cuda() for p in probs_host]
     engine = RolloutEngine(w, sampler, probabilities=probs)
     assert engine.fused
-    assert engine.step_kernel_name == ("HipTagContinuousTick" if full_obs else "HipTagContinuousTick_K10")
+    assert engine.step_kernel_name == ("HipTagContinuousTick" if full_obs else HEADLINE_TICK)
     orc = TagContinuousCOracle(E, n_threads=min(32, os.cpu_count() or 1), **cfg)
     np.testing.assert_array_equal(pull(w, OBS), orc.obs)
     rng_words = np.zeros(4 + E * N, dtype=np.uint32)
@@ -422,7 +440,7 @@ def test_headline_fused_tick_full_size(full_obs, E, ticks):
     assert near_tie <= max(2, rows // 100000), (near_tie, rows)
 
 
-def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed, kernel="HipTagContinuousTick_K10", before_tick=None):
+def _fused_ticks_vs_c_oracle(cfg, E, ticks, seed, kernel=HEADLINE_TICK, before_tick=None):
     """The fused tick (sample + step + reset in one launch) with the benchmark's uniform policy, every tick
     compared with the C oracle: sampled actions replayed, then state / observations / rewards / done /
     nearest_neighbor_ids and the post-reset state.  Returns (mean live agents per tick, id rows compared,
@@ -782,3 +800,52 @@ def test_host_restore_of_state_voids_the_cleared_row_flags():
     orc.timestep[:] = 40  # (_timestep_ was not restored)
     for t in range(40, 46):
         tick(t)
+
+
+@pytest.mark.parametrize("runners,K,levels,E,entry", [
+    (100, 10, 20, 257, "HipTagContinuousTickA_K10_N105A21"),   # the BASELINE shape: the entry with its sizes folded
+    (40, 7, 6, 61, "HipTagContinuousTickA_K8"),                # runtime sizes, K below the specialisation's
+    (200, 10, 20, 9, "HipTagContinuousTickA_K10_N512"),
+])
+def test_tick_on_given_actions_equals_the_sampling_tick(runners, K, levels, E, entry):
+    """`TickA` entries (step + restore of finished replicas on actions that are ALREADY in `sampled_actions`: the policy
+    forward's epilogue draws them, training/policy_kernel.py) against the sampling tick: the same actions give the same
+    arrays, bit for bit, through a whole episode and the restarts."""
+    import torch
+    from tests.hip_harness import ACT, OBS, REW, pull, require_gpu
+    from warp_drive_amd.env_wrapper import EnvWrapper
+    from warp_drive_amd.envs.tag_continuous import TagContinuous
+    from warp_drive_amd.managers.function_manager import HIPSampler
+    from warp_drive_amd.rollout import RolloutEngine
+    from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
+
+    require_gpu()
+    cfg = dict(num_taggers=5, num_runners=runners, grid_length=8.0, episode_length=30, seed=3, max_speed=0.5,
+               max_acceleration=0.2, min_acceleration=-0.2, num_acceleration_levels=levels, num_turn_levels=levels,
+               use_full_observation=False, num_other_agents_observed=K, tagging_distance=0.15, edge_hit_penalty=-0.1,
+               runner_exits_game_after_tagged=True)
+
+    def make(presampled):
+        w = EnvWrapper(env_obj=TagContinuous(**cfg), num_envs=E, env_backend="hip")
+        w.reset_all_envs()
+        sampler = HIPSampler(w.cuda_function_manager)
+        sampler.init_random(seed=21)
+        create_and_push_data_placeholders(env_wrapper=w, action_sampler=sampler, training_batch_size_per_env=None,
+                                          push_data_batch_placeholders=False)
+        return w, RolloutEngine(w, sampler, probabilities=None, presampled_actions=presampled)
+
+    (wa, ea), (wb, eb) = make(False), make(True)
+    assert eb.step_kernel_name == entry and ea.step_kernel_name == entry.replace("TickA", "Tick")
+    act_a = wa.cuda_data_manager.data_on_device_via_torch(ACT)
+    act_b = wb.cuda_data_manager.data_on_device_via_torch(ACT)
+    names = [n for n, _ in STATE] + [OBS, REW, "_done_", "_timestep_", "nearest_neighbor_ids", "num_runners"]
+    finished = 0
+    for t in range(70):
+        ea.run(1)                 # draws its actions (uniform probabilities) and steps
+        act_b.copy_(act_a)        # the same actions, given
+        eb.run(1)
+        torch.cuda.synchronize()
+        for n in names:
+            np.testing.assert_array_equal(pull(wb, n), pull(wa, n), err_msg=f"{n} t={t}")
+        finished += int((pull(wa, "_done_") > 0).sum())
+    assert finished >= 2 * E

@@ -81,6 +81,18 @@ def test_tag_continuous_picks_the_entry_point_by_agent_count_and_k():
     assert name(1000, 16) == "HipTagContinuousStep_K16_N1024" and name(1000, 17) == "HipTagContinuousStep"
     assert name(100, 10, full=True) == "HipTagContinuousStep"
 
+    # with a function manager that has it, the entry whose sizes are folded at compile time wins (BASELINE shape only)
+    class Manager:
+        def has_function(self, fname):
+            return fname == "HipTagContinuousStep_K10_N105A21"
+
+    env = TagContinuous(num_taggers=5, num_runners=100, num_other_agents_observed=10, use_full_observation=False, num_acceleration_levels=20, num_turn_levels=20, seed=1)
+    env.cuda_function_manager = Manager()
+    assert env.resolve_step_function_name("HipTagContinuousStep") == "HipTagContinuousStep_K10_N105A21"
+    env = TagContinuous(num_taggers=5, num_runners=100, num_other_agents_observed=9, use_full_observation=False, num_acceleration_levels=20, num_turn_levels=20, seed=1)
+    env.cuda_function_manager = Manager()
+    assert env.resolve_step_function_name("HipTagContinuousStep") == "HipTagContinuousStep_K10"
+
 
 def test_tag_continuous_lds_fits_a_workgroup_up_to_1024_agents():
     """the fused tick's LDS image: both probability slabs up to 256 agents, ONE slab beyond (the heads are sampled one

@@ -23,7 +23,6 @@
 // x all output rows: 4 KB per 32x32 tile, packed so that a lane reads the A operands of four
 // consecutive steps with one ds_read_b128), double-buffered with global_load_lds, shared by the four
 // wavefronts of a block.
-#pragma once
 #include "wd_common.h"
 
 namespace {

@@ -231,7 +231,9 @@ __device__ __forceinline__ void tc_fetch_slab(float *slab, const float *probs, c
 // of a 1005-agent replica with 21-way heads are 169 KB, and at ~510 agents half the LDS means two blocks per CU.
 __device__ __forceinline__ bool tc_one_slab(int N) { return N > 256; }
 
-template <bool FUSED>
+// FUSED: the launch also restores finished replicas; SAMPLE: it also draws the actions (false: they are read from
+// `actions`, e.g. drawn by the policy forward's epilogue -- csrc/kernels/policy_mlp.hip)
+template <bool FUSED, bool SAMPLE = FUSED>
 __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const TcFuse &fz, int env0, int epb,
                                                int N, int n_acc, int n_turn, int tid, float *slab_acc,
                                                float *slab_turn, bool want_cleared = false) {
@@ -266,10 +268,10 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
       in.tstep = a.timestep[env];
       in.nrun = a.num_runners[env];
     }
-    if (!FUSED) in.sampled = ((const int2 *)a.actions)[gi];
-    if (FUSED) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
+    if (!SAMPLE) in.sampled = ((const int2 *)a.actions)[gi];
+    if (SAMPLE) in.epoch = fz.rng_state[WD_RNG_HEADER + gi];
   }
-  if (FUSED) {
+  if (SAMPLE) {
     // this wavefront's rows of both probability slabs -> LDS (the second one later when they share the LDS)
     tc_fetch_slab(slab_acc, fz.probs_acc, a, env0, epb, N, n_acc, tid);
     if (!tc_one_slab(N)) tc_fetch_slab(slab_turn, fz.probs_turn, a, env0, epb, N, n_turn, tid);
@@ -340,6 +342,11 @@ __device__ __forceinline__ int2 tc_sample_heads(const TcArgs &a, const TcFuse &f
   if (tc_one_slab(a.N)) {  // block-uniform: the second head's rows replace the first head's (slab_turn == slab_acc)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wavefront's reads of its rows are complete
     __builtin_amdgcn_wave_barrier();
+    // Wavefront w's rows start at float 64 * w * n_actions: with heads of EQUAL size the two heads' rows of a
+    // wavefront coincide and are wave-private.  With unequal sizes w's turn rows overlap the acceleration rows of
+    // its neighbours: every wavefront must have sampled its first head (which also means every acceleration fetch
+    // has landed) before anybody fetches the second.  Block-uniform condition.
+    if (n_acc != n_turn) __syncthreads();
     tc_fetch_slab(slab_turn, fz.probs_turn, a, env0, epb, a.N, n_turn, threadIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -901,9 +908,14 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
 //           at +inf), as many trips as the fullest lane of the wavefront needs, U candidates per trip with the
 //           next trip's positions in flight.
 // At ~100 candidates this was measured and NOT adopted (a wash: pass 2 does not shrink with the number of
-// candidates); the break-even is at a few hundred.  What comes out is what the full chain
-// gives: every candidate within four key buckets of the radius is listed, so tc_resolve_keys sees the same first
-// K + 1 keys, and beyond them keys that are more than four buckets past the K-th (they cannot matter) or nothing.
+// candidates); the break-even is at a few hundred.  What comes out is the K set the full chain
+// gives: the result is accepted only if the K-th other agent found lies at least TWO key buckets inside the radius
+// (`held` at the call site), so every candidate that was NOT listed is strictly farther in float32 distance than the
+// K-th -- it can neither enter the K set nor tie with its last member -- and every candidate that can is listed and
+// ranked exactly by tc_resolve_keys.  The look-ahead entries may differ from the full chain's (an unlisted
+// candidate reads +inf there), so the 'apart' / 'simple' shortcuts can fire where the full chain would have run the
+// exact ranking: that changes the work, not the K set, because a look-ahead entry only ever decides whether keys
+// INSIDE the listed range need the exact comparison, and an entry at +inf says "no tie beyond here", which is true.
 // That the radius really held the K nearest is CHECKED afterwards (the K-th other agent found must lie inside it), so
 // the content of `knn_prev` is only a hint: stale, restored or overwritten rows cost time (the wavefront repeats the
 // search with the full chain), never exactness.
@@ -1550,7 +1562,7 @@ __device__ __forceinline__ void tc_gather_rows_sparse(const TcArgs &a, const TcF
 
 
 // EXACTK: K == KMAX, known at compile time (row offsets become immediates, the K-dependent selects fold away)
-template <int KMAX, bool FUSED, bool EXACTK, int IDB>
+template <int KMAX, bool FUSED, bool EXACTK, int IDB, bool SAMPLE = FUSED>
 __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, unsigned char *smem, int n_acc,
                                              int n_turn) {
   const int N = a.N, K = EXACTK ? KMAX : a.K;
@@ -1572,7 +1584,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   const size_t slab_turn_bytes = tc_align16((size_t)4 * epb * N * n_turn);
   const bool one_slab = tc_one_slab(N);
   const TcFastLds l = tc_carve_fast(smem, epb, N, K, n_waves,
-                                    !FUSED ? 0 : one_slab ? max(slab_acc_bytes, slab_turn_bytes) : slab_acc_bytes + slab_turn_bytes,
+                                    !SAMPLE ? 0 : one_slab ? max(slab_acc_bytes, slab_turn_bytes) : slab_acc_bytes + slab_turn_bytes,
                                     compact);
   const TcTables &tb = l.tb;
   float *const slab_acc = (float *)smem, *const slab_turn = (float *)(smem + (one_slab ? 0 : slab_acc_bytes));
@@ -1596,7 +1608,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   __builtin_amdgcn_s_setprio(3);
   WD_TC_PROBE_RT(16); WD_TC_PROBE(0); WD_TC_PROBE_HW(21);
   TcIn in;
-  tc_issue_loads<FUSED>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn, true);
+  tc_issue_loads<FUSED, SAMPLE>(in, a, fz, env0, epb, N, n_acc, n_turn, tid, slab_acc, slab_turn, true);
   const bool tab_in_lds = (n_acc <= WD_TC_TAB) && (n_turn <= WD_TC_TAB);
   const int n_taggers = tc_build_tables(tb, a, N, n_acc, n_turn, tab_in_lds, in);
   if (env0 >= a.E) return;  // whole block (no barrier is skipped by part of a block)
@@ -1612,7 +1624,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   if (compact && lane == 0) tb.live_cnt[wave] = __popcll(live_mask);
   if (FUSED) {
     if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
-    sampled = tc_sample_heads(a, fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn, env0, epb);
+    if (SAMPLE) sampled = tc_sample_heads(a, fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn, env0, epb);
   }
   WD_TC_PROBE(2);
   __syncthreads();  // tables are published; every wavefront is done with the slabs
@@ -1735,7 +1747,10 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         Tb = tc_knn_bound16<KMAX>(l.xy, N, sx, sy, pa, pb, K);
       }
       WD_TC_PROBE(7);
-      if (__ballot(searcher && Tb == 0x7f800000u) == 0ull) {  // every searcher of the wavefront has a radius
+      // every searcher of the wavefront has a radius -- and there IS a searcher: a wavefront without one (tid >=
+      // n_live: up to 11 of 16 at ~300 agents in the game) would run pass 1 over every candidate for nothing and
+      // compete for the VALU with the searching wavefronts of its SIMD; it goes straight to the barrier instead
+      if (__ballot(searcher) != 0ull && __ballot(searcher && Tb == 0x7f800000u) == 0ull) {
         // (lanes without a searcher: radius -1, nothing listed; they only take part in the wave-wide votes)
         // (candidates popped per trip: the fullest lane of a 32-candidate word holds ~2 at 1000 agents, ~4 at 500)
         constexpr int POPS = (IDB == 10) ? 1 : 2;
@@ -2287,79 +2302,108 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   fz.reset_table = (const TcResetEntry *)reset_table; fz.n_reset_arrays = n_reset_arrays;      \
   fz.stream_tag = stream_tag;
 
+// ---- entries.  This file is compiled into SEVERAL code objects (warp_drive_amd/build.py UNITS; a build of all of them
+// runs in parallel, and tuning one specialisation rebuilds one small object):
+//   (no WD_TC_KM)                      the generic entries HipTagContinuousStep / Tick: any N <= 1024, any K, full
+//                                      observations                                        -> wd_kernels_tc.hsaco
+//   -DWD_TC_KM=<k> -DWD_TC_WAVES=<w>   the fast entries for K <= k: `_K<k>` up to 128 agents (7 id bits in the search
+//        [-DWD_TC_BIG]                 keys), `_K<k>_N512` for 129 .. 512 (blocks of up to eight wavefronts, 9 id
+//                                      bits) and, with WD_TC_BIG, `_K<k>_N1024` beyond      -> wd_kernels_tc_k<k>.hsaco
+//   -DWD_TC_KM=<k> -DWD_TC_SHAPE_N=<n> -DWD_TC_SHAPE_A=<a>
+//                                      `_K<k>_N<n>A<a>`: ONE shape (n agents, exactly k observed, a-way action heads)
+//                                      with its sizes as compile-time constants -- what the reference gets for EVERY
+//                                      run by templating wkNumberAgents into the source it hands to nvcc
+//                                      (template_env_config.h:19-21); built ahead of time for the BASELINE shape
+//                                      (105 agents, K = 10, 21-way heads: -3.8 % per tick, experiments/README.md)
+//                                                                                           -> wd_kernels_tc_k10_n105a21.hsaco
+// Separate objects, so that work on the big-replica search never moves the registers or the code layout of the
+// headline kernel.  Every fast size class has three entries: Step (actions given), Tick (sample both heads + step +
+// restore finished replicas) and TickA (actions given -- drawn by the policy forward's epilogue, policy_mlp.hip --
+// + step + restore; same arguments as Tick, the sampler's are ignored).
 extern "C" {
 
-// generic entries: any N <= 1024, any K, and the full-observation mode
+#define WD_TC_CAT_(a, b) a##b
+#define WD_TC_CAT(a, b) WD_TC_CAT_(a, b)
+#define WD_TC_SMEM() extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[]
+
+#if !defined(WD_TC_KM)
+
 __global__ void HipTagContinuousStep(WD_TC_PARAMS) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  WD_TC_SMEM();
   WD_TC_PACK();
   tc_generic_impl<false>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
 __global__ void HipTagContinuousTick(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  WD_TC_SMEM();
   WD_TC_PACK();
   WD_TC_FUSE_PACK();
   tc_generic_impl<true>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);
 }
 
-// fast entries (partial observations, K <= KM); the host picks the smallest KM >= K and the entry for the replica size:
-// `_K<KM>` up to 128 agents (7 id bits in the search keys), `_K<KM>_N512` for 129 .. 512 (blocks of up to eight
-// wavefronts, 9 id bits), `_K<KM>_N1024` beyond.  Separate entries, so that work on the big-replica search never moves
-// the registers or the code layout of the headline kernel.
-#define WD_TC_SPECIALISE(KM, WAVES)                                                                 \
-  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM(WD_TC_PARAMS) {            \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    if (a.K == KM) tc_fast_impl<KM, false, true, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else tc_fast_impl<KM, false, false, 7>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-  }                                                                                            \
-  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    WD_TC_FUSE_PACK();                                                                         \
-    if (a.K == KM) tc_fast_impl<KM, true, true, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-    else tc_fast_impl<KM, true, false, 7>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-  }                                                                                            \
-  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousStep_K##KM##_N512(WD_TC_PARAMS) {     \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    tc_fast_impl<KM, false, false, 9>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-  }                                                                                            \
-  __global__ void __launch_bounds__(512, WAVES) HipTagContinuousTick_K##KM##_N512(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    WD_TC_FUSE_PACK();                                                                         \
-    tc_fast_impl<KM, true, false, 9>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+#elif defined(WD_TC_SHAPE_N)
+
+// one shape, sizes folded: N, K (exactly KM) and the two head sizes are constants from here on
+#define WD_TC_SHAPE_NAME(stem) WD_TC_CAT(WD_TC_CAT(WD_TC_CAT(WD_TC_CAT(WD_TC_CAT(stem, WD_TC_KM), _N), WD_TC_SHAPE_N), A), WD_TC_SHAPE_A)
+static_assert(WD_TC_SHAPE_N <= 128, "the shape-specialised entries use the 7-bit-id search of replicas up to 128 agents");
+__global__ void __launch_bounds__(512, 4) WD_TC_SHAPE_NAME(HipTagContinuousStep_K)(WD_TC_PARAMS) {
+  WD_TC_SMEM();
+  WD_TC_PACK();
+  a.N = WD_TC_SHAPE_N; a.K = WD_TC_KM;
+  tc_fast_impl<WD_TC_KM, false, true, 7>(a, TcFuse{}, tc_smem, WD_TC_SHAPE_A, WD_TC_SHAPE_A);
+}
+__global__ void __launch_bounds__(512, 4) WD_TC_SHAPE_NAME(HipTagContinuousTick_K)(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
+  WD_TC_SMEM();
+  WD_TC_PACK();
+  WD_TC_FUSE_PACK();
+  a.N = WD_TC_SHAPE_N; a.K = WD_TC_KM;
+  tc_fast_impl<WD_TC_KM, true, true, 7>(a, fz, tc_smem, WD_TC_SHAPE_A, WD_TC_SHAPE_A);
+}
+__global__ void __launch_bounds__(512, 4) WD_TC_SHAPE_NAME(HipTagContinuousTickA_K)(WD_TC_PARAMS WD_TC_FUSE_PARAMS) {
+  WD_TC_SMEM();
+  WD_TC_PACK();
+  WD_TC_FUSE_PACK();
+  a.N = WD_TC_SHAPE_N; a.K = WD_TC_KM;
+  tc_fast_impl<WD_TC_KM, true, true, 7, false>(a, fz, tc_smem, WD_TC_SHAPE_A, WD_TC_SHAPE_A);
+}
+
+#else
+
+#define WD_TC_NAME(stem, suffix) WD_TC_CAT(WD_TC_CAT(stem, WD_TC_KM), suffix)
+#define WD_TC_FAST_ENTRIES(suffix, THREADS, WAVES, IDB, SPLIT_EXACT)                                            \
+  __global__ void __launch_bounds__(THREADS, WAVES) WD_TC_NAME(HipTagContinuousStep_K, suffix)(WD_TC_PARAMS) {   \
+    WD_TC_SMEM();                                                                                                \
+    WD_TC_PACK();                                                                                                \
+    if (SPLIT_EXACT && a.K == WD_TC_KM)                                                                          \
+      tc_fast_impl<WD_TC_KM, false, SPLIT_EXACT, IDB>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+    else                                                                                                         \
+      tc_fast_impl<WD_TC_KM, false, false, IDB>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
+  }                                                                                                              \
+  __global__ void __launch_bounds__(THREADS, WAVES) WD_TC_NAME(HipTagContinuousTick_K, suffix)(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+    WD_TC_SMEM();                                                                                                \
+    WD_TC_PACK();                                                                                                \
+    WD_TC_FUSE_PACK();                                                                                           \
+    if (SPLIT_EXACT && a.K == WD_TC_KM)                                                                          \
+      tc_fast_impl<WD_TC_KM, true, SPLIT_EXACT, IDB>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);  \
+    else                                                                                                         \
+      tc_fast_impl<WD_TC_KM, true, false, IDB>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);        \
+  }                                                                                                              \
+  __global__ void __launch_bounds__(THREADS, WAVES) WD_TC_NAME(HipTagContinuousTickA_K, suffix)(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
+    WD_TC_SMEM();                                                                                                \
+    WD_TC_PACK();                                                                                                \
+    WD_TC_FUSE_PACK();                                                                                           \
+    tc_fast_impl<WD_TC_KM, true, false, IDB, false>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions);   \
   }
+// up to 128 agents: the entry branches once on "exactly KM observed" (the unrolled row layout of the usual case)
+WD_TC_FAST_ENTRIES(, 512, WD_TC_WAVES, 7, true)
+WD_TC_FAST_ENTRIES(_N512, 512, WD_TC_WAVES, 9, false)
+#if defined(WD_TC_BIG)
 // replicas of 513 .. 1024 agents: blocks of up to sixteen wavefronts (1024 threads: the reference's default geometry
 // serves up to 1024 agents per block, managers/function_manager.py:64-67), 10 id bits in the search keys (buckets of
 // 1024 ulps of d2: the exactness argument of tc_resolve_keys holds for any bucket width)
-#define WD_TC_SPECIALISE_BIG(KM)                                                                    \
-  __global__ void __launch_bounds__(1024, 4) HipTagContinuousStep_K##KM##_N1024(WD_TC_PARAMS) {       \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    tc_fast_impl<KM, false, false, 10>(a, TcFuse{}, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-  }                                                                                            \
-  __global__ void __launch_bounds__(1024, 4) HipTagContinuousTick_K##KM##_N1024(WD_TC_PARAMS WD_TC_FUSE_PARAMS) { \
-    extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];                    \
-    WD_TC_PACK();                                                                              \
-    WD_TC_FUSE_PACK();                                                                         \
-    tc_fast_impl<KM, true, false, 10>(a, fz, tc_smem, kNumAccelerationActions, kNumTurnActions); \
-  }
-WD_TC_SPECIALISE_BIG(4)
-WD_TC_SPECIALISE_BIG(8)
-WD_TC_SPECIALISE_BIG(10)
-WD_TC_SPECIALISE_BIG(12)
-WD_TC_SPECIALISE_BIG(16)
-WD_TC_SPECIALISE(2, 4)
-WD_TC_SPECIALISE(4, 4)
-WD_TC_SPECIALISE(6, 4)
-WD_TC_SPECIALISE(8, 4)
-WD_TC_SPECIALISE(10, 4)
-WD_TC_SPECIALISE(12, 3)
-WD_TC_SPECIALISE(16, 3)
-WD_TC_SPECIALISE(24, 2)
-WD_TC_SPECIALISE(32, 2)
+WD_TC_FAST_ENTRIES(_N1024, 1024, 4, 10, false)
+#endif
+
+#endif
 
 }  // extern "C"

@@ -15,6 +15,7 @@ the two differ by one ulp for ~0.07 % of inputs and only matter for exact near-t
 The device kernel squares the same way, so host and device agree with each other.
 """
 import copy
+import os
 
 import numpy as np
 
@@ -322,10 +323,20 @@ class TagContinuous(CUDAEnvironmentContext):
         if not self._fast_path():
             return default_name
         big = self.num_agents > 512
+        K = self.num_other_agents_observed
+        # the shape with its sizes folded at compile time, when the build has one (warp_drive_amd/build.py UNITS: the
+        # BASELINE shape, 105 agents / K = 10 / 21-way heads); WD_TC_SHAPE_ENTRIES=0 keeps the runtime-size entries
+        shaped = f"{default_name}_K{K}_N{self.num_agents}A{len(self.acceleration_actions)}"
+        fm = getattr(self, "cuda_function_manager", None)
+        if (self.SHAPE_ENTRIES and len(self.acceleration_actions) == len(self.turn_actions) and fm is not None
+                and fm.has_function(shaped)):
+            return shaped
         for k in (self._K_SPECIALISATIONS_N1024 if big else _K_SPECIALISATIONS):
-            if k >= self.num_other_agents_observed:
+            if k >= K:
                 return f"{default_name}_K{k}" + ("_N1024" if big else "_N512" if self.num_agents > 128 else "")
         return default_name
+
+    SHAPE_ENTRIES = os.environ.get("WD_TC_SHAPE_ENTRIES", "1") != "0"
 
     def lds_bytes(self, epb, fused=False, threads=None):
         """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve_fast /
@@ -390,21 +401,35 @@ class TagContinuous(CUDAEnvironmentContext):
         epb, block, _ = self._geometry()
         return self.lds_bytes(epb, fused=True, threads=block[0]) <= self.LDS_PER_WORKGROUP
 
+    def has_presampled_tick(self):
+        """True when this shape has a `TickA` entry: step + reset of finished replicas on actions that are already in
+        `sampled_actions` (drawn by the policy forward's epilogue, training/policy_kernel.py)"""
+        name = self.cuda_step.name.replace("Step", "TickA")
+        return self._fast_path() and self.cuda_function_manager.has_function(name)
+
     def tick_launch(self, sampler, probabilities, resetter, env_range=None):
         """Fused rollout tick: sample both action heads + step + reset finished replicas in ONE
         launch (HipTagContinuousTick[_K<k>]).  probabilities = [acceleration, turn] float32 CUDA
         tensors [E, N, n_actions].  `_done_` stays set for replicas that finished on the tick
-        (already reset); the next tick clears it."""
+        (already reset); the next tick clears it.
+        probabilities = None: the actions are NOT drawn here -- they are in `sampled_actions` already (the policy
+        forward's epilogue drew them, same counters, same search) -- and the launch is the `TickA` entry: step +
+        reset, nothing fetched or sampled."""
         from warp_drive_amd.managers.function_manager import _stream_tag
 
         fm, dm = self.cuda_function_manager, self.cuda_data_manager
-        name = self.cuda_step.name.replace("Step", "Tick")
+        presampled = probabilities is None
+        name = self.cuda_step.name.replace("Step", "TickA" if presampled else "Tick")
         fm.initialize_functions([name])
         fn = fm.get_function(name)
         _, reset_args, _, _ = resetter.fused_launch(dm, 0, 0)  # builds / refreshes the descriptor table
         table, n_arrays = reset_args[0], reset_args[1]
-        assert len(probabilities) == 2
         args, epb, block, grid = self._range_args(env_range)
+        if presampled:
+            null = np.uint64(0)
+            args = args + [null, null, null, table, n_arrays, _stream_tag("tick")]
+            return fn, args, block, grid, self.lds_bytes(epb, fused=False, threads=block[0])
+        assert len(probabilities) == 2
         args = args + [sampler.rng_state, probabilities[0], probabilities[1], table, n_arrays, _stream_tag("tick")]
         return fn, args, block, grid, self.lds_bytes(epb, fused=True, threads=block[0])
 

@@ -260,7 +260,7 @@ class HIPFunctionManager(CUDAFunctionManager):
         self._device_id = int(process_id if device_id is None else device_id)
         drv.ensure_init(self._device_id)
         self._module = None
-        self._extra_modules = None  # code objects of drv.EXTRA_HSACO_PATHS, loaded when a function is first asked for
+        self._extra_modules = None  # {path: Module} of the other code objects, loaded when a function is first asked for
         self._functions = {}
         self._function_names = []
 
@@ -312,21 +312,35 @@ class HIPFunctionManager(CUDAFunctionManager):
         for fname in func_names or []:
             if fname in self._functions:
                 continue
-            module = self._module
-            if not module.has_function(fname):  # a shape-specialised kernel of one of the extra code objects?
-                module = next((m for m in self._load_extra_modules() if m.has_function(fname)), self._module)
+            module = self._module_of(fname) or self._module
             self._functions[fname] = module.get_function(fname)  # (raises with the name when nobody has it)
             self._function_names.append(fname)
 
-    def _load_extra_modules(self):
+    def _module_of(self, fname):
+        """the loaded code object that holds kernel `fname`: the main one, or -- looked up in the build's manifest and
+        loaded on first use -- one of the others (warp_drive_amd/build.py UNITS); None when no object has it"""
+        if self._module.has_function(fname):
+            return self._module
         if self._extra_modules is None:
-            self._extra_modules = [drv.Module(p) for p in drv.EXTRA_HSACO_PATHS if os.path.exists(p)]
-        return self._extra_modules
+            self._extra_modules = {}
+        path = drv.code_object_of(fname)
+        if path is None or path == self._module.path:
+            return None
+        if path not in self._extra_modules:
+            self._extra_modules[path] = drv.Module(path)
+            logging.info(f"loaded the HIP code object {path}")
+        return self._extra_modules[path]
 
     def has_function(self, fname):
         if self._module is None:
             return False
-        return self._module.has_function(fname) or any(m.has_function(fname) for m in self._load_extra_modules())
+        return self._module.has_function(fname) or drv.code_object_of(fname) is not None
+
+    def code_object_path_of(self, fname):
+        """file the kernel `fname` was (or would be) loaded from -- what a counter record is keyed to"""
+        if self._module is not None and self._module.has_function(fname):
+            return self._module.path
+        return drv.code_object_of(fname)
 
     def global_address(self, name):
         """device address of a __device__ / __constant__ symbol of the MAIN code object (for kernels of the extra

@@ -17,9 +17,55 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libwdhip.so")
-HSACO_PATH = os.environ.get("WD_HSACO", os.path.join(_CSRC, "wd_kernels.hsaco"))  # override: experiments only
-# shape-specialised kernels in their own code objects (warp_drive_amd/build.py EXTRA_UNITS), loaded on demand
-EXTRA_HSACO_PATHS = (os.path.join(_CSRC, "wd_kernels_gw5.hsaco"),)
+# Code objects (warp_drive_amd/build.py UNITS): the MAIN one -- core services, TagGridWorld, Cartpole -- is loaded by
+# every function manager; the others (TagContinuous generic / per-K / shape-specialised, the trainer's policy kernels,
+# the 5-agent TagGridWorld rollout, the test kernels) are loaded when one of their kernels is first asked for.  Which
+# object holds a kernel is read from the manifest the build writes.  WD_HSACO_DIR (experiments only): a directory that
+# is searched first, so that a variant of ONE object can be measured against the others unchanged.
+_OVERRIDE_DIR = os.environ.get("WD_HSACO_DIR", "")
+MANIFEST_PATH = os.path.join(_CSRC, "wd_kernels.manifest.json")
+
+
+def code_object_path(basename):
+    if _OVERRIDE_DIR and os.path.exists(os.path.join(_OVERRIDE_DIR, basename)):
+        return os.path.join(_OVERRIDE_DIR, basename)
+    return os.path.join(_CSRC, basename)
+
+
+HSACO_PATH = code_object_path("wd_kernels.hsaco")
+_manifest = None
+
+
+def manifest():
+    """kernel name -> code object file name (csrc/wd_kernels.manifest.json)"""
+    global _manifest
+    if _manifest is None:
+        import json
+
+        if not os.path.exists(MANIFEST_PATH):
+            raise HipDriverError(f"{MANIFEST_PATH} is missing: build the kernels with warp_drive_amd.build")
+        _manifest = json.load(open(MANIFEST_PATH))
+    return _manifest
+
+
+def code_object_of(kernel_name):
+    """path of the code object that holds `kernel_name`, or None when no object of the build has it"""
+    name = manifest().get(kernel_name)
+    return None if name is None else code_object_path(name)
+
+
+def code_object_sha256(kernel_name):
+    """sha256 of the code object `kernel_name` is loaded from (the main object when the manifest does not know it):
+    what profiles/pmc_*.json records are keyed to"""
+    import hashlib
+
+    return hashlib.sha256(open(code_object_of(kernel_name) or HSACO_PATH, "rb").read()).hexdigest()
+
+
+def extra_code_objects():
+    """every code object of the build except the main one (sorted paths)"""
+    return sorted({code_object_path(n) for n in manifest().values()} - {HSACO_PATH})
+
 
 # every symbol include/wd_hip.h declares (tests assert the library exports them all)
 C_ABI_SYMBOLS = (

@@ -27,15 +27,18 @@ _ACTIONS = Constants.ACTIONS
 
 class RolloutEngine:
     def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
-                 rollout_batch=None, rollout_policy=None, ticks_per_launch=None):
+                 rollout_batch=None, rollout_policy=None, ticks_per_launch=None, presampled_actions=False):
         """probabilities: list (one per action head) of contiguous float32 CUDA tensors
         [n_envs, n_agents, n_actions_of_head]; None = uniform.  rollout_batch: the trainer's [T, E, ...] batch
         tensors for envs whose tick kernel fuses T ticks per launch and records every tick itself
         (CUDAClassicControlCartPoleEnv.tick_launch); rollout_policy: (packed weights, hidden width) of a small policy
         that such a kernel evaluates itself on every tick.  ticks_per_launch: env ticks per launch of THIS engine
         (None = the env object's own `ticks_per_launch` attribute); the env object is left as it was, so another
-        engine on the same wrapper is not affected."""
+        engine on the same wrapper is not affected.  presampled_actions: the tick does NOT draw the actions -- whoever
+        runs before it (the policy forward's epilogue, training/policy_kernel.py) has written `sampled_actions` -- and
+        is the env's step + reset entry (`env.has_presampled_tick()`)."""
         env = env_wrapper.env
+        self.presampled = bool(presampled_actions)
         saved = getattr(env, "ticks_per_launch", 1)
         if ticks_per_launch is not None:
             env.ticks_per_launch = int(ticks_per_launch)
@@ -84,13 +87,16 @@ class RolloutEngine:
             extra = {"batch": rollout_batch} if rollout_batch is not None else {}
             if rollout_policy is not None:
                 extra["policy"] = rollout_policy
-            fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, probabilities,
+            if self.presampled:
+                assert env_wrapper.env.has_presampled_tick(), "this env / shape has no step + reset entry for given actions"
+            fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, None if self.presampled else probabilities,
                                                                         env_wrapper.env_resetter, **extra)
             self.plan.add(fn, args, block, grid, shared)
             self.step_entry = 0
             self.step_kernel_name = fn.name
             self.entry_names.append(fn.name)
             return
+        assert not self.presampled, "presampled_actions needs the env's fused tick entry"
         for k, (p, a) in enumerate(zip(probabilities, head_sizes)):
             fn, args, block, grid, shared = sampler.categorical_launch(
                 p, actions, E * N, a, False, _stream_tag(f"{_ACTIONS}_{k}"), out_stride=H, out_offset=k)
