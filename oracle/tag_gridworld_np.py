@@ -134,3 +134,51 @@ class TagGridWorldOracle:
         self.obs = self.generate_observation()
         self.done = ((self.timestep >= self.T) | tag).astype(np.int32)  # :314
         return self.obs, self.rewards, self.done
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The live-policy rollout kernel (csrc/kernels/tag_gridworld_n5.hip, HipTagGridWorldRollout_N5_H32 / _H64) evaluates a
+# small two-hidden-layer policy per agent and tick.  Float32 restatement of that forward on the PACKED weights
+# (training/policy_kernel.py::pack_gridworld_policy), test infrastructure like cartpole_np.py::policy_probabilities.
+POLICY_IN, POLICY_IN_STRIDE, POLICY_ACTIONS = 21, 24, 5
+
+
+def policy_probabilities(packed, hidden, obs):
+    """obs [R, 21] float32 -> probabilities [R, 5] float32: acc = bias, one fused multiply-add per input in index
+    order (emulated in float64: the product of two float32 is exact there), ReLU, softmax with the maximum
+    subtracted, float32 running sum of the exponentials, one division per action -- what gw5_policy_cum computes"""
+    f32, H = np.float32, int(hidden)
+    w = np.asarray(packed, dtype=f32)
+    o = 0
+    W0 = w[o:o + H * POLICY_IN_STRIDE].reshape(H, POLICY_IN_STRIDE)[:, :POLICY_IN]; o += H * POLICY_IN_STRIDE
+    b0 = w[o:o + H]; o += H
+    W1 = w[o:o + H * H].reshape(H, H); o += H * H
+    b1 = w[o:o + H]; o += H
+    Wp = w[o:o + POLICY_ACTIONS * H].reshape(POLICY_ACTIONS, H); o += POLICY_ACTIONS * H
+    bp = w[o:o + POLICY_ACTIONS]
+
+    def layer(x, W, b):
+        acc = np.broadcast_to(b, (x.shape[0], W.shape[0])).astype(f32).copy()
+        for j in range(W.shape[1]):
+            acc = (W[None, :, j].astype(np.float64) * x[:, j:j + 1].astype(np.float64) + acc.astype(np.float64)).astype(f32)
+        return acc
+
+    x = np.asarray(obs, dtype=f32)
+    h1 = np.maximum(layer(x, W0, b0), f32(0))
+    h2 = np.maximum(layer(h1, W1, b1), f32(0))
+    logits = layer(h2, Wp, bp)
+    e = np.exp((logits - logits.max(axis=1, keepdims=True)).astype(f32)).astype(f32)
+    total = np.zeros(e.shape[0], f32)
+    for a in range(POLICY_ACTIONS):
+        total = (total + e[:, a]).astype(f32)
+    return (e / total[:, None]).astype(f32)
+
+
+def running_sums(p):
+    """the float32 running sums the inverse-CDF sampler compares the uniform with (random.cu:51-85)"""
+    c = np.zeros_like(p)
+    acc = np.zeros(p.shape[0], np.float32)
+    for a in range(p.shape[1]):
+        acc = p[:, a] if a == 0 else (acc + p[:, a]).astype(np.float32)
+        c[:, a] = acc
+    return c

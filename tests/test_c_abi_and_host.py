@@ -211,3 +211,34 @@ def test_config0_plumbing_cpu():
                 total_done += 1
                 e.reset()
     assert total_done >= 4
+
+
+def test_kernels_do_not_spill_to_scratch(built, tmp_path):
+    """Resource usage of every kernel of the build, read from the code objects' metadata notes: no VGPR spills and no
+    scratch (private segment) in the objects the BASELINE configs run -- the main one, the BASELINE-shape TagContinuous
+    entries, the TagGridWorld 5-agent rollouts (a reordering of two statements once cost the live-policy entry 5 483
+    spilled registers and 13 x its tick time without failing a single parity test), the policy kernels; a few bytes at
+    most anywhere else."""
+    import re
+
+    from warp_drive_amd import build as wd_build
+
+    llvm = os.path.join(wd_build.ROCM, "lib", "llvm", "bin")
+    strict = {"wd_kernels.hsaco", "wd_kernels_tc_k10_n105a21.hsaco", "wd_kernels_gw5.hsaco", "wd_kernels_mlp.hsaco"}
+    seen = 0
+    for obj in wd_build.UNITS:
+        elf = str(tmp_path / (obj + ".elf"))
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={built.code_object_path(obj)}",
+                        f"--output={elf}"], check=True, capture_output=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", elf], check=True, capture_output=True,
+                               text=True).stdout
+        names = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", notes)
+        kernels = [(n, int(p), int(v)) for n, p, v in names if not n.startswith(("_", "hidden"))]
+        kernels = [k for k in kernels if k[0] in built.manifest()]
+        assert kernels, obj
+        seen += len(kernels)
+        for name, private, spills in kernels:
+            limit = 0 if obj in strict else 64
+            assert private <= limit and spills <= (0 if obj in strict else 8), (obj, name, private, spills)
+    assert seen == len(built.manifest())

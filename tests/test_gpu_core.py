@@ -599,7 +599,7 @@ def test_integration_md_stub_verbatim():
     """INTEGRATION.md section 2 -- the ctypes binding a reference maintainer would add -- executed VERBATIM (raw
     ctypes on libwdhip.so: no managers, no hip_driver; only its `CSRC = ...` line points at this checkout), then
     TagGridWorld (5 agents, full observations) stepped through the stub's own `launch()` with device memory from
-    `wd_malloc` / `wd_memcpy_*`: positions, done and observations bit-exact against the oracle."""
+    `wd_malloc` / `wd_memcpy_*`: positions, done, observations and rewards bit-exact against the oracle."""
     import ctypes
     import os
     import re
@@ -649,12 +649,12 @@ def test_integration_md_stub_verbatim():
     threads = 64
     epb = threads // N
     lds = (4 * (4 * epb * N + 2 * epb + 2) + 15) // 16 * 16 + 4 * epb * N * F  # TagGridWorld.lds_bytes(epb)
-    f32, i32 = np.float32, np.int32
+    f64, i32 = np.float64, np.int32  # (the four reward scalars are float64 kernel arguments: tag_gridworld_rewards.h)
     rng = np.random.RandomState(3)
     for t in range(T + 3):
         a = rng.randint(0, 5, size=(E, N, 1)).astype(np.int32)
         act.push(a)
-        launch(fn, [x, y, act, done, rew, obs, f32(0.1), f32(10.0), f32(2.0), f32(0.01), i32(1), i32(L), tstep,
+        launch(fn, [x, y, act, done, rew, obs, f64(0.1), f64(10.0), f64(2.0), f64(0.01), i32(1), i32(L), tstep,
                     i32(T), i32(N), i32(E)], grid=((E + epb - 1) // epb,), block=(threads,), shared=lds)
         check(lib.wd_sync(torch.cuda.current_stream().cuda_stream), "sync")
         orc.step(a)
@@ -662,6 +662,7 @@ def test_integration_md_stub_verbatim():
         np.testing.assert_array_equal(y.pull(), orc.loc_y)
         np.testing.assert_array_equal(done.pull(), orc.done)
         np.testing.assert_array_equal(obs.pull(), orc.obs.astype(np.float32))
+        np.testing.assert_array_equal(rew.pull(), orc.rewards.astype(np.float32))
         if orc.done.any():  # (a tagged runner or the time-out ends a replica; the flags were just compared)
             break
     assert t >= 4 and orc.done.any(), t

@@ -118,6 +118,46 @@ def test_cartpole_trains_with_the_whole_batch_rollout_in_one_launch(tmp_path):
     assert abs(metrics["shared"]["Mean episodic reward"] - metrics2["shared"]["Mean episodic reward"]) < 8.0
 
 
+def test_gridworld_trains_with_the_whole_batch_rollout_in_one_launch(tmp_path):
+    """tag_gridworld with [32, 32] "tagger" / "runner" policies: both networks are evaluated inside the env's rollout
+    kernel (HipTagGridWorldRollout_N5_H32), one launch per training batch; the env-level rows it records are scattered
+    into the per-policy batches.  It must train, keep the per-tick path's episodic-reward bookkeeping (same random
+    start policies: episodic rewards of the same size), and `fused_rollout_policy: False` keeps the per-tick path; the
+    shipped [256, 256] policies take the per-tick path as well."""
+    small = {"to_train": True, "algorithm": "A2C", "lr": 0.005, "vf_loss_coeff": 1, "model": {"fc_dims": [32, 32]}}
+    ov = {"trainer": {"num_envs": 240, "train_batch_size": 240 * 25, "num_episodes": 400},
+          "env": {"episode_length": 50}, "policy": {"runner": dict(small), "tagger": dict(small)},
+          "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
+    torch.manual_seed(3)
+    trainer, metrics = _train("tag_gridworld", ov, tmp_path / "gw_one_launch", iters=4)
+    assert trainer._batch_rollout is not None and trainer._batch_rollout["split"] is not None
+    assert trainer.engine.step_kernel_name == "HipTagGridWorldRollout_N5_H32"
+    b = trainer.batch
+    assert b["tagger"]["obs"].shape[2] == 4 and b["runner"]["obs"].shape[2] == 1
+    # what the kernel recorded reached the per-policy batches: actions in range, observation rows that carry the
+    # agent's own "is me" one-hot (columns 15 .. 19 of a full observation row)
+    for pol, ids in (("tagger", [0, 1, 2, 3]), ("runner", [4])):
+        a = b[pol]["actions"][: trainer.batch_len]
+        assert int(a.min()) >= 0 and int(a.max()) <= 4
+        me = b[pol]["obs"][: trainer.batch_len, :, :, 15:20].argmax(dim=-1)
+        assert (me == torch.tensor(ids, device=me.device)[None, None, :]).all()
+    import math
+
+    for pol in ("tagger", "runner"):
+        assert math.isfinite(metrics[pol]["Total loss"]) and math.isfinite(metrics[pol]["Mean episodic reward"])
+    ov["trainer"]["fused_rollout_policy"] = False
+    torch.manual_seed(3)
+    trainer2, metrics2 = _train("tag_gridworld", ov, tmp_path / "gw_per_tick", iters=4)
+    assert trainer2._batch_rollout is None
+    for pol in ("tagger", "runner"):
+        a, c = metrics[pol]["Mean episodic reward"], metrics2[pol]["Mean episodic reward"]
+        assert abs(a - c) <= 0.35 * max(abs(a), abs(c), 1.0), (pol, a, c)
+    ov["trainer"]["fused_rollout_policy"] = True
+    ov["policy"] = {}
+    trainer3, _ = _train("tag_gridworld", ov, tmp_path / "gw_256", iters=1)
+    assert trainer3._batch_rollout is None   # [256, 256]: the per-tick path
+
+
 def test_graph_and_eager_rollouts_agree(tmp_path):
     """the hipGraph replay of a rollout tick must produce exactly what the eager tick produces"""
     from tests.hip_harness import require_gpu
@@ -168,6 +208,7 @@ def test_fused_policy_forward_in_the_rollout(tmp_path):
     for fused in (True, False):
         torch.manual_seed(0)
         ov["trainer"]["fused_policy_forward"] = fused
+        ov["trainer"]["fused_policy_forward_min_rows"] = 0  # (the default leaves policies with few rows to the framework)
         tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"f{int(fused)}"), verbose=False)
         assert all((f is not None) == fused for f in tr._fused_forward.values())
         tr._b_idx.zero_()

@@ -13,6 +13,7 @@
 // in HBM ([E, N, F] row-major) and leaves with flat, fully coalesced stores.  With the
 // reference geometry (block=(N,1,1), grid=(E,1)) epb is simply 1.
 #include "wd_common.h"
+#include "tag_gridworld_rewards.h"
 
 // action index -> (dx, dy); uploaded by the host like the reference
 // (kIndexToActionArr, tag_gridworld_step_pycuda.cu:6; env_cpu_gpu_consistency_checker.py:256-264)
@@ -70,8 +71,8 @@ template <bool FUSED>
 __device__ __forceinline__ void gw_step_impl(
     int *states_x_arr, int *states_y_arr, int *actions_arr,
     int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
-    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner,
+    double step_cost_for_tagger, int use_full_observation, int world_boundary,
     int *env_timestep_arr, int episode_length, int n_agents, int n_envs, const GwFuse &fz,
     int *s_mem) {
   const int N = n_agents;
@@ -94,13 +95,14 @@ __device__ __forceinline__ void gw_step_impl(
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const float L = (float)world_boundary;
+  GW_REWARD_TABLE(wall_hit_penalty, tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger);
 
   for (int env0 = blockIdx.x * epb; env0 < n_envs; env0 += gridDim.x * epb) {
     const int env = env0 + el;
     const bool active = (el < epb) && (env < n_envs);
     const int idx = env * N + ag;
     const int li = el * N + ag;
-    float rew = 0.0f;
+    bool hit = false;
     if (active) {
       int a;
       if (FUSED) {
@@ -129,7 +131,7 @@ __device__ __forceinline__ void gw_step_impl(
       const int uy = states_y_arr[idx] + kIndexToActionArr[2 * a + 1];
       const int cx = min(max(ux, 0), world_boundary);
       const int cy = min(max(uy, 0), world_boundary);
-      if (ux != cx || uy != cy) rew = -wall_hit_penalty;  // -1.0 * wall_hit_penalty * hit
+      hit = (ux != cx) || (uy != cy);  // :163-170
       states_x_arr[idx] = cx;
       states_y_arr[idx] = cy;
       s_x[li] = cx;
@@ -162,9 +164,7 @@ __device__ __forceinline__ void gw_step_impl(
         s_done[el] = fin ? 1 : 0;
       }
       // ---- rewards :180-187
-      const float base = (ag < N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
-                                      : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
-      rewards_arr[idx] = base + rew;
+      rewards_arr[idx] = GW_REWARD(ag < N - 1, tag, hit);
       // ---- this agent's observation row :194-275
       const float tnorm = (float)t / (float)episode_length;
       // (two calls, so the LDS image and the HBM row keep their own address spaces -- a pointer
@@ -209,7 +209,7 @@ __device__ __forceinline__ void gw_step_impl(
 // Needs the LDS observation image (rows of up to ~60 floats).  n_actions <= 8.
 __device__ __forceinline__ void gw_rollout_impl(
     int *states_x_arr, int *states_y_arr, int *actions_arr, int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner, float step_cost_for_tagger,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner, double step_cost_for_tagger,
     int use_full_observation, int world_boundary, int *env_timestep_arr, int episode_length, int n_agents,
     int n_envs, const GwFuse &fz, int ticks, float *obs_batch, int *action_batch, float *reward_batch,
     int *done_batch, int reset_cache_dwords, int *s_mem) {
@@ -233,6 +233,7 @@ __device__ __forceinline__ void gw_rollout_impl(
   const int tid = threadIdx.x, T_ = blockDim.x;
   const int el = tid / N, ag = tid - el * N;
   const float L = (float)world_boundary;
+  GW_REWARD_TABLE(wall_hit_penalty, tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger);
   const uint32_t k0 = fz.rng_state[0], k1 = fz.rng_state[1];
   // the action table (host-uploadable __constant__ memory) once per launch, in scalar registers: indexed by the
   // sampled action inside the tick loop it is a global load that waits for every store of the tick (the memory
@@ -306,7 +307,8 @@ __device__ __forceinline__ void gw_rollout_impl(
       } else {
         for (int q = tid; q < n_out; q += T_) wd_store_untracked(brow + q, s_obs[q]);
       }
-      float rew = 0.0f, fx = 0.0f, fy = 0.0f;
+      float fx = 0.0f, fy = 0.0f;
+      bool hit = false;
       int a = 0;
       bool fin_mine = false;
       if (active) {
@@ -324,7 +326,7 @@ __device__ __forceinline__ void gw_rollout_impl(
         for (int i = 1; i < 5; ++i) { ddx = (a == i) ? act_dx[i] : ddx; ddy = (a == i) ? act_dy[i] : ddy; }
         const int ux = x + ddx, uy = y + ddy;
         const int cx = min(max(ux, 0), world_boundary), cy = min(max(uy, 0), world_boundary);
-        if (ux != cx || uy != cy) rew = -wall_hit_penalty;
+        hit = (ux != cx) || (uy != cy);
         x = cx;
         y = cy;
         s_x[li] = cx;
@@ -362,10 +364,8 @@ __device__ __forceinline__ void gw_rollout_impl(
           wd_store_untracked(done_batch + ((long)k * n_envs + env), fin ? 1 : 0);
         }
         last_done = fin ? 1 : 0;
-        const float base = (ag < N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
-                                        : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
-        wd_store_untracked(reward_batch + ((long)k * n_envs * N + idx), base + rew);
-        last_reward = base + rew;
+        last_reward = GW_REWARD(ag < N - 1, tag, hit);
+        wd_store_untracked(reward_batch + ((long)k * n_envs * N + idx), last_reward);
         last_action = a;
         const float tnorm = (float)t / (float)episode_length;
         if (use_full_observation) {
@@ -449,8 +449,8 @@ extern "C" {
 __global__ void HipTagGridWorldStep(
     int *states_x_arr, int *states_y_arr, int *actions_arr,
     int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
-    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner,
+    double step_cost_for_tagger, int use_full_observation, int world_boundary,
     int *env_timestep_arr, int episode_length, int n_agents, int n_envs) {
   extern __shared__ __attribute__((aligned(16))) int gw_smem[];
   gw_step_impl<false>(states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty,
@@ -463,8 +463,8 @@ __global__ void HipTagGridWorldStep(
 __global__ void HipTagGridWorldTick(
     int *states_x_arr, int *states_y_arr, int *actions_arr,
     int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
-    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner,
+    double step_cost_for_tagger, int use_full_observation, int world_boundary,
     int *env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
     const float *probs, int n_actions, const void *reset_table, int n_reset_arrays, int stream_tag) {
   extern __shared__ __attribute__((aligned(16))) int gw_smem[];
@@ -481,8 +481,8 @@ __global__ void HipTagGridWorldTick(
 __global__ void HipTagGridWorldRollout(
     int *states_x_arr, int *states_y_arr, int *actions_arr,
     int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner,
-    float step_cost_for_tagger, int use_full_observation, int world_boundary,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner,
+    double step_cost_for_tagger, int use_full_observation, int world_boundary,
     int *env_timestep_arr, int episode_length, int n_agents, int n_envs, uint32_t *rng_state,
     const float *probs, int n_actions, const void *reset_table, int n_reset_arrays, int stream_tag,
     int ticks, float *obs_batch, int *action_batch, float *reward_batch, int *done_batch, int reset_cache_dwords) {

@@ -23,7 +23,23 @@
 //     inside the loop.  The host checks that the registered reset arrays are exactly those three.
 // Semantics, recording and random draws are those of HipTagGridWorldRollout (same arguments + the action table's
 // device address, which lives in the main code object); parity: tests/test_gpu_gridworld.py, same test, same oracle.
+//
+// LIVE POLICY (`HipTagGridWorldRollout_N5_H32` / `_H64`, the TagGridWorld counterpart of
+// HipClassicControlCartPoleEnvRollout_H32 / _H64 in cartpole.hip): every tick evaluates a small network on the agent's
+// current observation row instead of reading fixed probabilities -- policy forward, sampling, step, restart and
+// recording of a whole training batch in ONE launch (the reference runs a framework forward + sampler + step + reset
+// launches + three synchronisations per tick, trainer_base.py:383-428).  Two policies, as in the reference's
+// TagGridWorld training config (run_configs/tag_gridworld.yaml: "tagger" for agents 0 - 3, "runner" for agent 4): two
+// hidden layers of H = 32 or 64 ReLU units + one softmax head of 5 actions each.  Packed weights per policy
+// (training/policy_kernel.py::pack_gridworld_policy): W0 [H][24] (rows of the 21 inputs, padded to 24 floats so that
+// every row starts on a 16-byte boundary; the padding is never read), b0 [H], W1 [H][H], b1 [H], Wp [5][H], bp [5],
+// float32, the block padded to a multiple of four floats.  Both sets live in LDS for the whole launch; a lane reads
+// its own policy's.  Arithmetic: acc = bias, then one fmaf per input in index order; softmax with the maximum
+// subtracted, expf, one division per action -- restated in oracle/tag_gridworld_np.py::policy_probabilities.
+// Measured (profiles/r05_prepared_items_first_call.txt, 1000 replicas, 20 ticks per launch): 10.9 us per tick at
+// H = 32, 30.1 at H = 64 -- the trainer's per-tick path costs 390 - 490 us per tick of the same replicas.
 #include "wd_common.h"
+#include "tag_gridworld_rewards.h"
 
 namespace {
 
@@ -38,22 +54,95 @@ constexpr int GW5_N = 5, GW5_F = 21, GW5_EPB = 12;
 constexpr int GW5_ROW = GW5_N * GW5_F;        // 105 floats: one replica's observation rows
 constexpr int GW5_IMG = GW5_EPB * GW5_ROW;    // 1260 floats: the block's observation image
 constexpr int GW5_MAX_COORD = 63;             // cells per axis - 1 the quotient table (and the packed cell) holds
+constexpr int GW5_IN_STRIDE = 24;             // floats per row of W0 (21 inputs + padding)
+constexpr int GW5_ACTIONS = 5;
 
-}  // namespace
+// floats of one policy's packed weights, rounded up to whole 16-byte vectors (the second policy starts aligned)
+__host__ __device__ constexpr int gw5_policy_floats(int H) {
+  return (H * GW5_IN_STRIDE + H + H * H + H + GW5_ACTIONS * H + GW5_ACTIONS + 3) & ~3;
+}
 
-extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
+// running float32 sums of the action probabilities of one agent: w = its policy's packed weights (LDS), x = its
+// observation row (LDS, 21 floats)
+template <int H>
+__device__ __forceinline__ void gw5_policy_cum(const float *w, const float *x, float (&cumv)[8]) {
+  const float *W0 = w, *b0 = W0 + H * GW5_IN_STRIDE, *W1 = b0 + H, *b1 = W1 + H * H, *Wp = b1 + H, *bp = Wp + GW5_ACTIONS * H;
+  float in[GW5_F];
+#pragma unroll
+  for (int j = 0; j < GW5_F; ++j) in[j] = x[j];
+  float h1[H], h2[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    float acc = b0[i];
+#pragma unroll
+    for (int j = 0; j < 20; j += 4) {
+      const float4 wr = *(const float4 *)(W0 + i * GW5_IN_STRIDE + j);
+      acc = fmaf(wr.x, in[j], acc); acc = fmaf(wr.y, in[j + 1], acc);
+      acc = fmaf(wr.z, in[j + 2], acc); acc = fmaf(wr.w, in[j + 3], acc);
+    }
+    acc = fmaf(W0[i * GW5_IN_STRIDE + 20], in[20], acc);
+    h1[i] = fmaxf(acc, 0.0f);
+  }
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    float acc = b1[i];
+#pragma unroll
+    for (int j = 0; j < H; j += 4) {
+      const float4 wr = *(const float4 *)(W1 + i * H + j);
+      acc = fmaf(wr.x, h1[j], acc); acc = fmaf(wr.y, h1[j + 1], acc);
+      acc = fmaf(wr.z, h1[j + 2], acc); acc = fmaf(wr.w, h1[j + 3], acc);
+    }
+    h2[i] = fmaxf(acc, 0.0f);
+  }
+  float logit[GW5_ACTIONS], m = -__builtin_inff();
+#pragma unroll
+  for (int a = 0; a < GW5_ACTIONS; ++a) {
+    float acc = bp[a];
+#pragma unroll
+    for (int j = 0; j < H; j += 4) {
+      const float4 wr = *(const float4 *)(Wp + a * H + j);
+      acc = fmaf(wr.x, h2[j], acc); acc = fmaf(wr.y, h2[j + 1], acc);
+      acc = fmaf(wr.z, h2[j + 2], acc); acc = fmaf(wr.w, h2[j + 3], acc);
+    }
+    logit[a] = acc;
+    m = fmaxf(m, acc);
+  }
+  float e[GW5_ACTIONS], sum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < GW5_ACTIONS; ++a) {
+    e[a] = expf(logit[a] - m);
+    sum += e[a];
+  }
+  float cum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    if (a < GW5_ACTIONS) {
+      const float p = e[a] / sum;
+      cum = (a == 0) ? p : cum + p;
+    }
+    cumv[a] = cum;
+  }
+}
+
+
+// H = 0: fixed probabilities (`probs`); H = 32 / 64: the live policies
+template <int H>
+__device__ __forceinline__ void gw5_rollout(
     int *states_x_arr, int *states_y_arr, int *actions_arr, int *done_arr, float *rewards_arr, float *obs_arr,
-    float wall_hit_penalty, float tag_reward_for_tagger, float tag_penalty_for_runner, float step_cost_for_tagger,
+    double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner, double step_cost_for_tagger,
     int use_full_observation, int world_boundary, int *env_timestep_arr, int episode_length, int n_agents, int n_envs,
     uint32_t *rng_state, const float *probs, int n_actions, const void *reset_table, int n_reset_arrays,
     int stream_tag, int ticks, float *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
-    int reset_cache_dwords, const int *action_table) {
-  extern __shared__ __attribute__((aligned(16))) float gw5_smem[];
+    int reset_cache_dwords, const int *action_table, const float *policy_tagger, const float *policy_runner,
+    float *gw5_smem) {
   const int CD = reset_cache_dwords;                        // dwords per replica in the restore cache
   float *const s_obs = gw5_smem;                            // [12][5][21] the block's observation image (16-byte aligned)
   uint32_t *const s_cache = (uint32_t *)(s_obs + GW5_IMG);  // [12][CD] the rows finished replicas are restored from
   float *const s_div = (float *)(s_cache + GW5_EPB * CD);   // [64] c / L
   float *const s_tn = s_div + GW5_MAX_COORD + 1;            // [episode_length + 1] t / episode_length
+  // the two policies' packed weights behind the tables, on a 16-byte boundary (host: the same arithmetic)
+  float *const s_pol = s_tn + ((episode_length + 1 + 3) & ~3);  // [2][gw5_policy_floats(H)]: tagger, runner
+  GW_REWARD_TABLE(wall_hit_penalty, tag_reward_for_tagger, tag_penalty_for_runner, step_cost_for_tagger);
   const int lane = threadIdx.x;                             // (blocks are one wavefront)
   const int el = lane / GW5_N, ag = lane - el * GW5_N;      // local replica (12 = none), agent
   const Gw5ResetEntry *const table = (const Gw5ResetEntry *)reset_table;
@@ -65,6 +154,12 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
     const float L = (float)world_boundary;
     if (lane <= world_boundary) s_div[lane] = (float)lane / L;
     for (int q = lane; q <= episode_length; q += 64) s_tn[q] = (float)q / (float)episode_length;
+    if constexpr (H > 0) {
+      for (int q = lane; q < gw5_policy_floats(H); q += 64) {
+        s_pol[q] = policy_tagger[q];
+        s_pol[gw5_policy_floats(H) + q] = policy_runner[q];
+      }
+    }
   }
 
   for (int env0 = blockIdx.x * GW5_EPB; env0 < n_envs; env0 += gridDim.x * GW5_EPB) {
@@ -86,12 +181,14 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
       y = states_y_arr[idx];
       t = env_timestep_arr[env];
       epoch0 = rng_state[WD_RNG_HEADER + idx];
-      const float *row = probs + (long)idx * n_actions;
-      float cum = 0.0f;  // the running float32 sums of the (fixed) probabilities, once per launch
+      if constexpr (H == 0) {
+        const float *row = probs + (long)idx * n_actions;
+        float cum = 0.0f;  // the running float32 sums of the (fixed) probabilities, once per launch
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < n_actions) cum = (i == 0) ? row[0] : cum + row[i];
-        cumv[i] = cum;
+        for (int i = 0; i < 8; ++i) {
+          if (i < n_actions) cum = (i == 0) ? row[0] : cum + row[i];
+          cumv[i] = cum;
+        }
       }
     }
     for (int q = lane; q < n_out; q += 64) s_obs[q] = obs_blk[q];  // the observation the first action is sampled on
@@ -118,8 +215,11 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
     // every value loaded above is consumed HERE: the wait for a load whose first use is inside the tick loop is placed
     // inside the loop and -- the memory counter returns in order -- waits for the previous tick's stores on every trip
     asm volatile("" : "+v"(x), "+v"(y), "+v"(t), "+v"(epoch0));
+    if constexpr (H == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(cumv[i]));
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(cumv[i]));
+    }
+    const float *const my_policy = s_pol + ((ag == GW5_N - 1) ? gw5_policy_floats(H) : 0);  // runner : tagger
     float last_reward = 0.0f;
     int last_action = 0, last_done = 0;
     float *const rep = s_obs + min(el, GW5_EPB - 1) * GW5_ROW;  // this lane's replica's five rows
@@ -127,7 +227,9 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
     const int runner_lane = min(el * GW5_N + GW5_N - 1, 63);
 
     for (int k = 0; k < ticks; ++k) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tick's image writes / restores, before this tick's record reads
+      // the previous tick's image writes / restores, before this tick's record reads (the fixed-policy entry's statement of
+      // what holds anyway -- LDS operations of one wavefront execute in issue order; it compiles to nothing there)
+      if constexpr (H == 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // ---- record the observation of this tick (flat, coalesced; none of the record stores is tracked).  The usual
       // case -- the block's slice of the row is a whole number of 16-byte vectors on a 16-byte boundary -- reads its
       // (up to) five vectors per lane with all LDS reads in flight, then stores them; a loop of read / wait / store
@@ -145,16 +247,21 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
       } else {
         for (int q = lane; q < n_out; q += 64) wd_store_untracked(brow + q, s_obs[q]);
       }
-      float rew = 0.0f;
+      bool hit = false;
       int a = 0;
       if (active) {
+        const int n_act = (H > 0) ? GW5_ACTIONS : n_actions;
         // ---- sample (random.cu:51-85), the draw of tick k of T single-tick launches
         const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)idx, epoch0 + (uint32_t)k, (uint32_t)stream_tag, k0, k1,
                                                         blk, blk_quad));
+        // the LIVE policy on this tick's observation row (the image still holds what was recorded above).  AFTER the
+        // draw: placed in front of it (the Philox refill is a branch) the scheduler hoists the network's ~1 500 LDS
+        // operand reads over the whole block and the allocator spills 5 483 registers at H = 64 (13 x the tick time)
+        if constexpr (H > 0) gw5_policy_cum<H>(my_policy, rep + ag * GW5_F, cumv);
         int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cnt += (i < n_actions && cumv[i] < u) ? 1 : 0;
-        a = min(cnt, n_actions - 1);
+        for (int i = 0; i < 8; ++i) cnt += (i < n_act && cumv[i] < u) ? 1 : 0;
+        a = min(cnt, n_act - 1);
         wd_store_untracked(action_batch + ((long)k * n_envs * GW5_N + idx), a);
         // ---- movement :152-173
         int ddx = act_dx[0], ddy = act_dy[0];
@@ -162,7 +269,7 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
         for (int i = 1; i < 5; ++i) { ddx = (a == i) ? act_dx[i] : ddx; ddy = (a == i) ? act_dy[i] : ddy; }
         const int ux = x + ddx, uy = y + ddy;
         const int cx = min(max(ux, 0), world_boundary), cy = min(max(uy, 0), world_boundary);
-        if (ux != cx || uy != cy) rew = -wall_hit_penalty;
+        hit = (ux != cx) || (uy != cy);  // :163-170
         x = cx;
         y = cy;
         t += 1;  // :295
@@ -176,10 +283,8 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
       if (active) {
         if (ag == 0) wd_store_untracked(done_batch + ((long)k * n_envs + env), fin ? 1 : 0);
         last_done = fin ? 1 : 0;
-        const float base = (ag < GW5_N - 1) ? (tag ? tag_reward_for_tagger : -step_cost_for_tagger)
-                                            : (tag ? -tag_penalty_for_runner : step_cost_for_tagger);
-        wd_store_untracked(reward_batch + ((long)k * n_envs * GW5_N + idx), base + rew);
-        last_reward = base + rew;
+        last_reward = GW_REWARD(ag < GW5_N - 1, tag, hit);
+        wd_store_untracked(reward_batch + ((long)k * n_envs * GW5_N + idx), last_reward);
         last_action = a;
         // ---- the image: only the positions and the time change from tick to tick (the type and "is me" columns are
         // constants that arrived with the image and return with a restore); this lane's agent is column ag (x) and
@@ -222,3 +327,33 @@ extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(
     __syncthreads();  // (the next trip overwrites the image and the cache)
   }
 }
+
+}  // namespace
+
+#define GW5_PARAMS                                                                                                    \
+  int *states_x_arr, int *states_y_arr, int *actions_arr, int *done_arr, float *rewards_arr, float *obs_arr,          \
+      double wall_hit_penalty, double tag_reward_for_tagger, double tag_penalty_for_runner,                           \
+      double step_cost_for_tagger, int use_full_observation, int world_boundary, int *env_timestep_arr,               \
+      int episode_length, int n_agents, int n_envs, uint32_t *rng_state, const float *probs, int n_actions,           \
+      const void *reset_table, int n_reset_arrays, int stream_tag, int ticks, float *obs_batch, int *action_batch,    \
+      float *reward_batch, int *done_batch, int reset_cache_dwords, const int *action_table
+#define GW5_ARGS                                                                                                      \
+  states_x_arr, states_y_arr, actions_arr, done_arr, rewards_arr, obs_arr, wall_hit_penalty, tag_reward_for_tagger,   \
+      tag_penalty_for_runner, step_cost_for_tagger, use_full_observation, world_boundary, env_timestep_arr,           \
+      episode_length, n_agents, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks,  \
+      obs_batch, action_batch, reward_batch, done_batch, reset_cache_dwords, action_table
+
+extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5(GW5_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) float gw5_smem[];
+  gw5_rollout<0>(GW5_ARGS, nullptr, nullptr, gw5_smem);
+}
+// the same arguments + the packed weights of the two policies; dynamic LDS = the fixed-policy kernel's, its time
+// table rounded up to 16 bytes, + 2 * gw5_policy_floats(H) floats (envs/tag_gridworld.py::tick_launch)
+#define GW5_POLICY_ENTRY(HH)                                                                                          \
+  extern "C" __global__ void __launch_bounds__(64) HipTagGridWorldRollout_N5_H##HH(                                   \
+      GW5_PARAMS, const float *policy_tagger, const float *policy_runner) {                                           \
+    extern __shared__ __attribute__((aligned(16))) float gw5_smem[];                                                  \
+    gw5_rollout<HH>(GW5_ARGS, policy_tagger, policy_runner, gw5_smem);                                                \
+  }
+GW5_POLICY_ENTRY(32)
+GW5_POLICY_ENTRY(64)

@@ -129,6 +129,13 @@ class TagGridWorld:
         return obs, rew, done, {}
 
 
+def gridworld_policy_floats(hidden):
+    """floats of one packed policy of the live-policy rollout kernel (gw5_policy_floats in tag_gridworld_n5.hip):
+    W0 [H][24], b0 [H], W1 [H][H], b1 [H], Wp [5][H], bp [5], rounded up to whole 16-byte vectors"""
+    H = int(hidden)
+    return (H * 24 + H + H * H + H + 5 * H + 5 + 3) // 4 * 4
+
+
 _STEP_ARGS = [
     _LOC_X, _LOC_Y, _ACTIONS, "_done_", _REWARDS, _OBSERVATIONS, "wall_hit_penalty",
     "tag_reward_for_tagger", "tag_penalty_for_runner", "step_cost_for_tagger", "use_full_observation",
@@ -172,20 +179,42 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         with_image = tables + 4 * A * F
         return with_image if with_image <= 60000 else tables  # WD_GW_IMAGE_MAX_BYTES
 
+    def _step_args(self):
+        """the step kernel's positional arguments.  The four reward scalars go in as FLOAT64 -- the env's own Python
+        floats, not the float32 copies the data manager holds -- so that the kernel can form `reward_tag +
+        reward_penalty` the way the CPU step does (float64, narrowed once: csrc/kernels/tag_gridworld_rewards.h)."""
+        args = list(self.cuda_step_function_feed(_STEP_ARGS))
+        first = _STEP_ARGS.index("wall_hit_penalty")
+        args[first:first + 4] = [np.float64(self.wall_hit_penalty), np.float64(self.tag_reward_for_tagger),
+                                 np.float64(self.tag_penalty_for_runner), np.float64(self.step_cost_for_tagger)]
+        return args
+
     def step_launch(self):
         """(function, args, block, grid, shared_bytes) of one device step."""
         epb, block, grid = self._geometry()
-        return self.cuda_step, self.cuda_step_function_feed(_STEP_ARGS), block, grid, self.lds_bytes(epb)
+        return self.cuda_step, self._step_args(), block, grid, self.lds_bytes(epb)
 
     ticks_per_launch = 1    # > 1 (with batch tensors): fixed-policy rollout, T ticks fused per launch
 
-    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None):
+    ROLLOUT_POLICY_WIDTHS = (32, 64)   # HipTagGridWorldRollout_N5_H<width>
+    ROLLOUT_POLICY_PACKING = "gridworld"   # training.policy_kernel.pack_gridworld_policy
+
+    def rollout_policy_groups(self):
+        """agents the live-policy rollout kernel evaluates ONE network for, in its argument order: the taggers, the
+        runner (run_configs/tag_gridworld.yaml maps them to the "tagger" / "runner" policies)"""
+        return [list(range(self.num_agents - 1)), [self.num_agents - 1]]
+
+    def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None, policy=None):
         """Fused rollout tick: sample the action + step + reset finished replicas in ONE launch
         (HipTagGridWorldTick).  probabilities = [float32 CUDA tensor [E, N, n_actions]].  `_done_`
         stays set for replicas that finished on the tick (already reset); the next tick clears it.
         With `ticks_per_launch` > 1 and `batch` = {"obs": [T, E, N, F] float32, "actions": [T, E, N, 1] int32,
         "rewards": [T, E, N] float32, "done": [T, E] int32} (env-level batch tensors, T >= ticks_per_launch) the
-        launch is HipTagGridWorldRollout: T ticks of a fixed-policy rollout, tick k recorded in row k."""
+        launch is HipTagGridWorldRollout: T ticks of a fixed-policy rollout, tick k recorded in row k.
+        `policy` (optional, 5 agents / full observations only) = ((packed tagger policy, packed runner policy), hidden
+        width) -- float32 CUDA tensors from training.policy_kernel.pack_gridworld_policy: the launch evaluates the two
+        policy networks itself on every tick's observation rows (HipTagGridWorldRollout_N5_H<width>) instead of reading
+        `probabilities`."""
         from warp_drive_amd.managers.function_manager import _stream_tag
 
         assert env_range is None, "replica ranges are a TagContinuous experiment"
@@ -200,7 +229,7 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         if rollout and self._specialised_rollout_shape():
             # the specialised rollout kernel runs blocks of ONE wavefront (12 replicas) at every batch size
             epb, block, grid = 12, (64, 1, 1), ((int(dm.meta_info("n_envs")) + 11) // 12, 1)
-        args = list(self.cuda_step_function_feed(_STEP_ARGS)) + [
+        args = self._step_args() + [
             sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0], reset_args[1],
             _stream_tag("tick")]
         if rollout:
@@ -226,6 +255,19 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
                 cache_dwords = 0
             args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"], np.int32(cache_dwords)]
             special = self._specialised_rollout(name, block, cache_dwords)
+            if policy is not None:
+                (tagger, runner), width = policy
+                assert special is not None, "the live-policy rollout exists for 5 agents with full observations only"
+                assert width in self.ROLLOUT_POLICY_WIDTHS and int(probabilities[0].shape[-1]) == 5
+                n_w = gridworld_policy_floats(width)
+                for t in (tagger, runner):
+                    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n_w
+                special = f"{special}_H{width}"
+                fm.initialize_functions([special])
+                # the fixed-policy kernel's LDS with the time table rounded up to 16 bytes, then the two policies
+                lds5 = 4 * (epb * N * F + epb * cache_dwords + 64 + (int(self.episode_length) + 1 + 3) // 4 * 4 + 2 * n_w)
+                return (fm.get_function(special), args + [fm.global_address("kIndexToActionArr"), tagger, runner], block,
+                        grid, (lds5 + 15) // 16 * 16)
             if special is not None:
                 # the kernel specialised for this shape (csrc/kernels/tag_gridworld_n5.hip, its own code object):
                 # same arguments + the device address of the action table the host uploads into the main code object
@@ -234,6 +276,7 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
                 return (fm.get_function(special), args + [fm.global_address("kIndexToActionArr")], block, grid,
                         (lds5 + 15) // 16 * 16)
             return fm.get_function(name), args, block, grid, lds
+        assert policy is None, "the live-policy rollout needs ticks_per_launch > 1 and the batch tensors"
         return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
 
     SPECIALISED_ROLLOUT = os.environ.get("WD_GW_ROLLOUT_N5", "1") != "0"  # False: always the general rollout kernel

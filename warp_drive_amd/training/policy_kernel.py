@@ -150,3 +150,25 @@ def pack_rollout_policy(model, out=None):
         return flat.contiguous()
     out.copy_(flat)
     return out
+
+
+@torch.no_grad()
+def pack_gridworld_policy(model, out=None):
+    """One policy of the live-policy TagGridWorld rollout (csrc/kernels/tag_gridworld_n5.hip::gw5_policy_cum): W0
+    [H][24] (the 21 inputs of a row padded to 24 floats: every row starts on a 16-byte boundary), b0 [H], W1 [H][H],
+    b1 [H], Wp [5][H], bp [5], float32, the block padded to a multiple of four floats.  `out`: refill in place."""
+    from warp_drive_amd.envs.tag_gridworld import gridworld_policy_floats
+
+    w0, b0 = model.fc["0"][0].weight, model.fc["0"][0].bias
+    H = w0.shape[0]
+    assert w0.shape[1] == 21 and model.policy_head[0].weight.shape == (5, H)
+    w0p = torch.zeros((H, 24), dtype=torch.float32, device=w0.device)
+    w0p[:, :21] = w0.detach().float()
+    parts = [w0p, b0, model.fc["1"][0].weight, model.fc["1"][0].bias, model.policy_head[0].weight, model.policy_head[0].bias]
+    flat = torch.cat([t.detach().float().reshape(-1) for t in parts])
+    n = gridworld_policy_floats(H)
+    if out is None:
+        out = torch.zeros(n, dtype=torch.float32, device=w0.device)
+    assert out.numel() == n
+    out[: flat.numel()].copy_(flat)
+    return out

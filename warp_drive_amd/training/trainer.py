@@ -31,7 +31,8 @@ from warp_drive_amd.training.data_loader import create_and_push_data_placeholder
 from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
-from warp_drive_amd.training.policy_kernel import FusedPolicyForward, pack_rollout_policy, rollout_policy_width
+from warp_drive_amd.training.policy_kernel import (FusedPolicyForward, pack_gridworld_policy, pack_rollout_policy,
+                                                    rollout_policy_width)
 from warp_drive_amd.utils.constants import Constants
 
 _ACTIONS, _REWARDS, _OBSERVATIONS = Constants.ACTIONS, Constants.REWARDS, Constants.OBSERVATIONS
@@ -200,29 +201,69 @@ class Trainer:
             for pol in self.policies:
                 m = self._inference_model(pol)
                 obs_size = flattened_obs_size(env_wrapper.env.observation_space[self.policy_map[pol][0]])
-                if FusedPolicyForward.supports(m, obs_size) and self.obs.dtype == torch.float32:
+                rows = E * len(self.policy_map[pol])
+                if (FusedPolicyForward.supports(m, obs_size) and self.obs.dtype == torch.float32
+                        and rows >= int(tcfg.get("fused_policy_forward_min_rows", 0))):
                     self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size)
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
-        # ---- whole-batch rollout in ONE launch: envs whose tick kernel can evaluate a small policy itself
-        # (Cartpole: two hidden layers of 32 / 64 units, one head; csrc/kernels/cartpole.hip) run all
-        # `batch_len` ticks of a training batch -- policy forward, sampling, step, reset, recording of the
-        # batch rows -- in a single launch.  `trainer.fused_rollout_policy: False` keeps the per-tick path.
+        # ---- whole-batch rollout in ONE launch: envs whose tick kernel can evaluate small policies itself (Cartpole:
+        # csrc/kernels/cartpole.hip; TagGridWorld with 5 agents and full observations: tag_gridworld_n5.hip -- two hidden
+        # layers of 32 / 64 units, one head) run all `batch_len` ticks of a training batch -- policy forward, sampling,
+        # step, reset, recording of the batch rows -- in a single launch.  `trainer.fused_rollout_policy: False` keeps
+        # the per-tick path.
         self._batch_rollout = None
+        self._setup_batch_rollout(env_wrapper, tcfg)
+
+    def _setup_batch_rollout(self, env_wrapper, tcfg):
         env = env_wrapper.env
-        if (bool(tcfg.get("fused_rollout_policy", True)) and self.engine.fused and len(self.policies) == 1
-                and hasattr(env, "ROLLOUT_POLICY_WIDTHS") and self._rollout_dtype is None and self.batch_len > 1):
-            pol = self.policies[0]
+        if not (bool(tcfg.get("fused_rollout_policy", True)) and self.engine.fused and self._rollout_dtype is None
+                and hasattr(env, "ROLLOUT_POLICY_WIDTHS") and self.batch_len > 1 and len(self.head_sizes) == 1
+                and self.head_sizes[0] <= 8):
+            return
+        # the agent groups the kernel evaluates one network for, in its argument order; every group must be exactly
+        # covered by ONE policy of the trainer (one policy may serve several groups)
+        groups = getattr(env, "rollout_policy_groups", lambda: [list(range(env_wrapper.n_agents))])()
+        owners = []
+        for g in groups:
+            owner = [p for p in self.policies if set(g) <= set(self.policy_map[p])]
+            if len(owner) != 1:
+                return
+            owners.append(owner[0])
+        if set(owners) != set(self.policies) or sum(len(g) for g in groups) != env_wrapper.n_agents:
+            return
+        widths = set()
+        for pol in self.policies:
             obs_size = flattened_obs_size(env.observation_space[self.policy_map[pol][0]])
-            width = rollout_policy_width(self.models[pol], obs_size, env.ROLLOUT_POLICY_WIDTHS)
-            if width is not None and len(self.head_sizes) == 1 and self.head_sizes[0] <= 8:
-                packed = pack_rollout_policy(self.models[pol]).to(self.device)
-                batch = {"obs": self.batch[pol]["obs"], "actions": self.batch[pol]["actions"],
+            widths.add(rollout_policy_width(self.models[pol], obs_size, env.ROLLOUT_POLICY_WIDTHS))
+        if len(widths) != 1 or None in widths:
+            return
+        width = widths.pop()
+        pack = pack_gridworld_policy if getattr(env, "ROLLOUT_POLICY_PACKING", "") == "gridworld" else pack_rollout_policy
+        packed = {pol: pack(self.models[pol]).to(self.device) for pol in self.policies}
+        E, N, T = self.num_envs, env_wrapper.n_agents, self.batch_len
+        if len(self.policies) == 1:
+            pol = self.policies[0]  # the per-policy batch tensors ARE the env-level ones
+            env_batch = {"obs": self.batch[pol]["obs"], "actions": self.batch[pol]["actions"],
                          "rewards": self.batch[pol]["rewards"], "done": self.done_batch}
-                self.engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
-                                            rollout_batch=batch, rollout_policy=(packed, width),
-                                            ticks_per_launch=self.batch_len)  # (the env object keeps its own setting)
-                self._batch_rollout = {"policy": pol, "packed": packed}
-                self._want_graph = False
+            split = None
+        else:  # the kernel records env-level rows; they are scattered into the per-policy batches after the launch
+            F = int(self.obs.reshape(E, N, -1).shape[-1])
+            env_batch = {"obs": torch.zeros((T, E, N, F), dtype=torch.float32, device=self.device),
+                         "actions": torch.zeros((T, E, N, 1), dtype=torch.int32, device=self.device),
+                         "rewards": torch.zeros((T, E, N), dtype=torch.float32, device=self.device),
+                         "done": self.done_batch}
+            split = env_batch
+        arg = packed[owners[0]] if len(groups) == 1 else [packed[o] for o in owners]
+        try:
+            engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
+                                   rollout_batch=env_batch, rollout_policy=(arg, width),
+                                   ticks_per_launch=self.batch_len)  # (the env object keeps its own setting)
+        except AssertionError as err:  # e.g. TagGridWorld with another shape: the kernel does not exist for it
+            logging.info(f"whole-batch rollout not available for this shape ({err}); using the per-tick path")
+            return
+        self.engine = engine
+        self._batch_rollout = {"packed": packed, "pack": pack, "split": split}
+        self._want_graph = False
 
     # --------------------------------------------------------------------------- rollout
     def _inference_model(self, pol):
@@ -296,27 +337,32 @@ class Trainer:
 
     @torch.no_grad()
     def _generate_rollout_batch_in_one_launch(self):
-        """the whole batch of ticks as ONE launch (the kernel evaluates the policy itself), then the episodic
+        """the whole batch of ticks as ONE launch (the kernel evaluates the policies itself), then the episodic
         reward bookkeeping of `_tick`, vectorised over the recorded rows"""
         br = self._batch_rollout
-        pol = br["policy"]
-        pack_rollout_policy(self.models[pol], out=br["packed"])  # the weights of this iteration
+        for pol in self.policies:
+            br["pack"](self.models[pol], out=br["packed"][pol])  # the weights of this iteration
         self.engine.run(1)
         T = self.batch_len
-        r = self.batch[pol]["rewards"][:T]                       # [T, E, n]
         d = self.done_batch[:T] > 0                              # [T, E]
-        total = torch.cumsum(r, dim=0) + self._ep_reward[pol][None]  # reward since the last start carried in
         idx = torch.arange(T, device=self.device)[:, None].expand(T, self.num_envs)
         last = torch.where(d, idx, torch.full_like(idx, -1)).cummax(dim=0).values   # latest finished tick <= t
         prev = torch.cat([torch.full_like(last[:1], -1), last[:-1]], dim=0)         # ... < t
-        base = torch.gather(total, 0, prev.clamp(min=0)[..., None].expand_as(total))
-        base = torch.where((prev >= 0)[..., None], base, torch.zeros_like(base))
-        episode = total - base                                   # reward of the running episode up to tick t
-        self._ep_sum[pol] += (episode.mean(dim=2) * d).sum()
-        self._ep_cnt += d.sum()
         end = last[-1]                                           # [E]
-        carried = torch.gather(total, 0, end.clamp(min=0)[None, :, None].expand(1, *total.shape[1:]))[0]
-        self._ep_reward[pol] = torch.where((end >= 0)[:, None], total[-1] - carried, total[-1])
+        for pol in self.policies:
+            if br["split"] is not None:  # env-level rows -> this policy's batch tensors
+                ids = self.ids[pol]
+                for key in ("obs", "actions", "rewards"):
+                    self.batch[pol][key][:T].copy_(br["split"][key][:T].index_select(2, ids))
+            r = self.batch[pol]["rewards"][:T]                       # [T, E, n]
+            total = torch.cumsum(r, dim=0) + self._ep_reward[pol][None]  # reward since the last start carried in
+            base = torch.gather(total, 0, prev.clamp(min=0)[..., None].expand_as(total))
+            base = torch.where((prev >= 0)[..., None], base, torch.zeros_like(base))
+            episode = total - base                                   # reward of the running episode up to tick t
+            self._ep_sum[pol] += (episode.mean(dim=2) * d).sum()
+            carried = torch.gather(total, 0, end.clamp(min=0)[None, :, None].expand(1, *total.shape[1:]))[0]
+            self._ep_reward[pol] = torch.where((end >= 0)[:, None], total[-1] - carried, total[-1])
+        self._ep_cnt += d.sum()
 
     def _generate_rollout_batch(self):
         if self._batch_rollout is not None:
