@@ -1,13 +1,17 @@
 """Trainer at configs[2] (2000 replicas, 50-tick batches = 100 000 env-steps per iteration): the rollout
 (policy forward + fused env tick + bookkeeping) and one whole training iteration, float32 (reference
-semantics) vs bf16-autocast update.  Run on the GPU box; the output is kept as profiles/r03_rollout_timing.txt."""
+semantics) vs bf16-autocast update.  Run on the GPU box; the output is kept as profiles/r0N_rollout_timing.txt."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from warp_drive_amd.training.scripts.train import setup_trainer
-for update, rollout, fused in (("float32", "float32", True), ("bfloat16", "float32", True), ("bfloat16", "bfloat16", False)):
+CASES = [("float32", "float32", True, True), ("float32", "float32", True, False), ("bfloat16", "float32", True, True),
+         ("bfloat16", "bfloat16", False, False)]
+if len(sys.argv) > 1:
+    CASES = CASES[: int(sys.argv[1])]
+for update, rollout, fused, fast in CASES:
     ov = {"trainer": {"num_envs": 2000, "train_batch_size": 100000, "rollout_dtype": rollout, "update_dtype": update,
-                      "fused_policy_forward": fused}}
-    tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt_{update}_{rollout}_{int(fused)}", verbose=False)
+                      "fused_policy_forward": fused, "fused_tick": fast}}
+    tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt_{update}_{rollout}_{int(fused)}_{int(fast)}", verbose=False)
     tr._generate_rollout_batch(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): tr._generate_rollout_batch()
@@ -19,7 +23,7 @@ for update, rollout, fused in (("float32", "float32", True), ("bfloat16", "float
     tr.train(4)
     torch.cuda.synchronize()
     it = (time.perf_counter() - t0) / 4
-    print(f"update_dtype={update} rollout_dtype={rollout} fused_policy_forward={fused}: rollout of {tr.batch_len} ticks = {dt*1e3:.1f} ms "
+    print(f"update_dtype={update} rollout_dtype={rollout} fused_policy_forward={fused} fused_tick={tr._fast_tick is not None}: rollout of {tr.batch_len} ticks = {dt*1e3:.1f} ms "
           f"-> {dt/tr.batch_len*1e3:.3f} ms/tick, {tr.train_batch_size/dt:.3e} env-steps/s; training iteration {it*1e3:.0f} ms "
-          f"(rollout {(s0.rollout_time - r0)/4*1e3:.0f} + update {(s0.training_time - u0)/4*1e3:.0f}) -> {tr.train_batch_size/it:.3e} env-steps/s end to end")
+          f"(rollout {(s0.rollout_time - r0)/4*1e3:.0f} + update {(s0.training_time - u0)/4*1e3:.0f}) -> {tr.train_batch_size/it:.3e} env-steps/s end to end", flush=True)
     tr.graceful_close()

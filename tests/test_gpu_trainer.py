@@ -4,6 +4,7 @@ import glob
 import os
 
 import pytest
+import numpy as np
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -209,6 +210,7 @@ def test_fused_policy_forward_in_the_rollout(tmp_path):
         torch.manual_seed(0)
         ov["trainer"]["fused_policy_forward"] = fused
         ov["trainer"]["fused_policy_forward_min_rows"] = 0  # (the default leaves policies with few rows to the framework)
+        ov["trainer"]["fused_tick"] = False  # (this test compares the probability tensors: the three-launch tick never writes them)
         tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"f{int(fused)}"), verbose=False)
         assert all((f is not None) == fused for f in tr._fused_forward.values())
         tr._b_idx.zero_()
@@ -306,3 +308,55 @@ def test_inference_forward_on_device():
     for a, b in zip(probs, probs_b):
         assert b.dtype == torch.float32 and float((a.detach() - b).abs().max()) < 2e-2
         np.testing.assert_allclose(b.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def test_three_launch_tick_equals_the_per_op_tick(tmp_path):
+    """`trainer.fused_tick` (all policies' forward in one launch with the actions drawn in its epilogue -> the env's
+    step + reset entry on given actions -> one bookkeeping kernel) against the path it replaces (a forward launch per
+    policy writing probabilities, the env's sampling tick, ~20 framework ops): the SAME probabilities go through the
+    SAME Philox counters and the same inverse-CDF search, so the two trainers must stay bit-identical -- sampled
+    actions, every batch row (observations, actions, rewards, done), the generator's epochs, the env state -- through
+    two whole rollouts that include episode ends, and their episodic-reward metric must agree."""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers import hip_driver as drv
+    from warp_drive_amd.training.scripts.train import setup_trainer
+
+    require_gpu()
+    ov = {"trainer": {"num_envs": 37, "train_batch_size": 37 * 12, "num_episodes": 40, "seed": 11,
+                      "fused_policy_forward_min_rows": 0},
+          "env": {"num_runners": 59, "episode_length": 9, "num_other_agents_observed": 10},
+          "saving": {"metrics_log_freq": 100, "model_params_save_freq": 0}}
+    trainers = {}
+    for fast in (True, False):
+        torch.manual_seed(0)
+        ov["trainer"]["fused_tick"] = fast
+        tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"t{int(fast)}"), verbose=False)
+        assert (tr._fast_tick is not None) == fast
+        trainers[fast] = tr
+    a, b = trainers[True], trainers[False]
+    assert a._presampled_engine.step_kernel_name.startswith("HipTagContinuousTickA_K10")
+    assert b.engine.step_kernel_name.startswith("HipTagContinuousTick_K10")
+    def words(tr):
+        out = np.zeros(4 + tr.num_envs * tr.w.n_agents, dtype=np.uint32)
+        drv.memcpy_dtoh(out, tr.sampler.rng_state)
+        torch.cuda.synchronize()
+        return out
+
+    for rollout in range(2):
+        for tr in (a, b):
+            tr._generate_rollout_batch()
+        torch.cuda.synchronize()
+        assert int(a._b_idx.item()) == a.batch_len == int(b._b_idx.item())
+        np.testing.assert_array_equal(words(a), words(b))
+        assert torch.equal(a.actions, b.actions) and torch.equal(a.obs, b.obs) and torch.equal(a.done_batch, b.done_batch)
+        assert int((a.done_batch > 0).sum()) >= a.num_envs  # episodes did end inside the batch
+        for pol in a.policies:
+            for key in ("obs", "actions", "rewards"):
+                assert torch.equal(a.batch[pol][key][: a.batch_len], b.batch[pol][key][: b.batch_len]), (rollout, pol, key)
+            assert torch.equal(a._ep_reward[pol], b._ep_reward[pol])
+            assert torch.allclose(a._ep_sum[pol].sum(), b._ep_sum[pol].sum(), rtol=1e-5)
+        assert torch.equal(a._ep_cnt, b._ep_cnt) and float(a._ep_cnt.sum()) > 0
+    for tr in (a, b):  # and it trains
+        m = tr.train(2)
+        assert all(np.isfinite(m[pol]["Total loss"]) for pol in tr.policies)
+        tr.graceful_close()

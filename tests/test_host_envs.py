@@ -188,26 +188,28 @@ def test_gridworld_rollout_kernel_choice():
 
 
 @pytest.mark.parametrize("hidden", [32, 64])
-def test_prepared_gridworld_policy_packing_matches_the_framework_model(hidden):
-    """experiments/gw5_policy (the live-policy TagGridWorld rollout, prepared for the next round): the packed layout
-    and the float32 restatement of the in-kernel forward reproduce training.models.FullyConnected to rounding"""
-    import sys
-
+def test_gridworld_policy_packing_matches_the_framework_model(hidden):
+    """the live-policy TagGridWorld rollout (csrc/kernels/tag_gridworld_n5.hip): the packed layout
+    (training/policy_kernel.py::pack_gridworld_policy) and the oracle's float32 restatement of the in-kernel forward
+    (oracle/tag_gridworld_np.py::policy_probabilities) reproduce training.models.FullyConnected to rounding"""
     import torch
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "gw5_policy"))
-    import policy_oracle as po
+    from oracle.tag_gridworld_np import policy_probabilities, running_sums
+    from warp_drive_amd.envs.tag_gridworld import gridworld_policy_floats
     from warp_drive_amd.training.models import FullyConnected
+    from warp_drive_amd.training.policy_kernel import pack_gridworld_policy
 
     torch.manual_seed(hidden)
     model = FullyConnected(21, [5], [hidden, hidden])
-    packed = po.pack_model(model)
-    assert packed.size == po.policy_floats(hidden) and packed.size % 4 == 0
+    packed = pack_gridworld_policy(model).numpy()
+    assert packed.size == gridworld_policy_floats(hidden) and packed.size % 4 == 0
+    again = torch.full((packed.size,), 7.0)
+    assert np.array_equal(pack_gridworld_policy(model, out=again).numpy(), packed)  # refill in place
     x = np.random.RandomState(1).rand(40, 21).astype(np.float32)
-    p = po.probabilities(packed, hidden, x)
+    p = policy_probabilities(packed, hidden, x)
     with torch.no_grad():
         q = model.forward_inference(torch.from_numpy(x))[0]
     q = (q[0] if isinstance(q, (list, tuple)) else q).numpy()
     assert np.abs(p - q).max() < 1e-6
-    c = po.running_sums(p)
+    c = running_sums(p)
     assert (np.diff(c, axis=1) >= 0).all() and np.abs(c[:, -1] - 1).max() < 1e-6

@@ -114,6 +114,14 @@ struct MlpArgs {
   float *values;          // [n_rows] or null
   float *obs_out;         // [T, n_rows, F] training-batch copy of the rows, or null
   const long long *batch_row;  // device counter: which T-row of obs_out (null: row 0)
+  // ---- actions drawn in the epilogue (two heads; rng_state null: no sampling).  Same counters, same search as the
+  // env's fused tick (tag_continuous.hip::tc_sample_heads): Philox counter (row, epoch, stream_tag, 3), words 0 / 1 for
+  // the two heads, inverse CDF on the float32 running sum of the probabilities this kernel would have written
+  uint32_t *rng_state;    // seed words + one epoch counter per (replica, agent) row
+  int *actions;           // [E * N, 2] the env's `sampled_actions`
+  int *act_out;           // [T, n_rows, 2] training-batch copy, or null
+  int stream_tag;
+  int tile0;              // first 32-row tile of THIS policy in the launch (several policies share one launch)
 };
 
 // TN1 / TN2: hidden widths / 32; KT1: ceil(F / 32)
@@ -123,7 +131,7 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
   constexpr int CHUNK = (TN1 > TN2 ? TN1 : TN2) * 1024;  // floats per LDS buffer
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
   float *const buf0 = lds, *const buf1 = lds + CHUNK;
-  const int g = (blockIdx.x * (blockDim.x >> 6) + wave) * 32 + j;  // policy-local row of this lane's column
+  const int g = ((int)(blockIdx.x * (blockDim.x >> 6) + wave) - p.tile0) * 32 + j;  // policy-local row of this lane's column
   const bool valid = g < p.n_rows;
   const int gc = valid ? g : p.n_rows - 1;
   const int env = gc / p.n_pol, a = gc - env * p.n_pol;
@@ -262,11 +270,31 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
   if (h == 0) tile_rows[j] = valid ? (int)src_row : -1;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  if (p.rng_state) {
+    // lane (agent of the tile, head): 32 agents x 2 heads = the wavefront.  The tile row holds both heads'
+    // probabilities (stride 65: lanes of different agents hit different banks)
+    const int ag = lane & 31, head = lane >> 5;
+    const int row = tile_rows[ag];
+    if (row >= 0) {
+      const uint32_t epoch = p.rng_state[WD_RNG_HEADER + row];
+      const wd_u4 rnd = wd_philox4x32_10(wd_u4{(uint32_t)row, epoch, (uint32_t)p.stream_tag, 3u}, p.rng_state[0],
+                                         p.rng_state[1]);
+      const int a = wd_slab_sample(tile + ag * TS + (head ? r1 : 0), head ? p.A1 : p.A0,
+                                   wd_u01_open_closed(head ? rnd.y : rnd.x));
+      p.actions[2 * (long)row + head] = a;
+      if (p.act_out) {
+        const long long t = p.batch_row ? *p.batch_row : 0;
+        p.act_out[2 * ((long)t * p.n_rows + (g - j + ag)) + head] = a;
+      }
+      if (head == 0) p.rng_state[WD_RNG_HEADER + row] = epoch + 1u;
+    }
+  }
 #pragma unroll 1
   for (int head = 0; head < 2; ++head) {
     const int A = head ? p.A1 : p.A0, off = head ? r1 : 0;
     if (A == 0) break;
     float *const out = head ? p.probs1 : p.probs0;
+    if (out == nullptr) continue;  // (the actions were drawn above: nobody reads the probabilities)
     const int per_pass = 64 / A;                  // agents per store instruction (heads are <= 63 wide)
     const int sub = (int)(((float)lane + 0.5f) / (float)A), col = lane - sub * A;  // lane -> (agent of the pass, column)
     for (int a0 = 0; a0 < 32; a0 += per_pass) {
@@ -291,7 +319,32 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
   MlpArgs p;                                                                                          \
   p.obs = obs; p.F = F; p.N = N; p.agent_ids = agent_ids; p.id0 = id0; p.n_pol = n_pol; p.n_rows = n_rows;         \
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.A0 = A0; p.A1 = A1;             \
-  p.probs0 = probs0; p.probs1 = probs1; p.values = values; p.obs_out = obs_out; p.batch_row = batch_row;
+  p.probs0 = probs0; p.probs1 = probs1; p.values = values; p.obs_out = obs_out; p.batch_row = batch_row; \
+  p.rng_state = nullptr; p.actions = nullptr; p.act_out = nullptr; p.stream_tag = 0; p.tile0 = 0;
+
+// HipPolicyMlpAct_*: ALL policies of a rollout tick in ONE launch (blocks [0, first_block_b) serve policy A, the rest
+// policy B; first_block_b >= gridDim.x: one policy) with the actions drawn in the epilogue: the probabilities never
+// leave the chip (probs0 / probs1 null) and the env's tick is its step + reset entry on given actions
+// (`TickA`, tag_continuous.hip).  One launch instead of one per policy: a policy with few rows (10 000 tagger rows
+// = a third of a round of blocks) no longer costs a whole round.
+#define WD_MLP_ACT_PARAMS                                                                             \
+  const float *obs, int F, int N, int A0, int A1, float *probs0, float *probs1, const long long *batch_row, \
+      uint32_t *rng_state, int *actions, int stream_tag, int first_block_b,                           \
+      const int *a_agent_ids, int a_id0, int a_n_pol, int a_n_rows, const float *a_w1, const float *a_b1, \
+      const float *a_w2, const float *a_b2, const float *a_w3, const float *a_b3, float *a_obs_out, int *a_act_out, \
+      const int *b_agent_ids, int b_id0, int b_n_pol, int b_n_rows, const float *b_w1, const float *b_b1, \
+      const float *b_w2, const float *b_b2, const float *b_w3, const float *b_b3, float *b_obs_out, int *b_act_out
+#define WD_MLP_ACT_PACK()                                                                             \
+  const bool second = (int)blockIdx.x >= first_block_b; /* block-uniform: scalar selects */           \
+  MlpArgs p;                                                                                          \
+  p.obs = obs; p.F = F; p.N = N; p.A0 = A0; p.A1 = A1; p.probs0 = probs0; p.probs1 = probs1;          \
+  p.values = nullptr; p.batch_row = batch_row; p.rng_state = rng_state; p.actions = actions;          \
+  p.stream_tag = stream_tag; p.tile0 = second ? first_block_b * (int)(blockDim.x >> 6) : 0;           \
+  p.agent_ids = second ? b_agent_ids : a_agent_ids; p.id0 = second ? b_id0 : a_id0;                   \
+  p.n_pol = second ? b_n_pol : a_n_pol; p.n_rows = second ? b_n_rows : a_n_rows;                      \
+  p.w1 = second ? b_w1 : a_w1; p.b1 = second ? b_b1 : a_b1; p.w2 = second ? b_w2 : a_w2;              \
+  p.b2 = second ? b_b2 : a_b2; p.w3 = second ? b_w3 : a_w3; p.b3 = second ? b_b3 : a_b3;              \
+  p.obs_out = second ? b_obs_out : a_obs_out; p.act_out = second ? b_act_out : a_act_out;
 
 extern "C" {
 // HipPolicyMlp_<H1>x<H2>_k<KT1>: hidden widths H1, H2; observation rows of up to 32 * KT1 floats.
@@ -301,6 +354,11 @@ extern "C" {
   __global__ void __launch_bounds__(256, 1) HipPolicyMlp_##H1##x##H2##_k##KT1(WD_MLP_PARAMS) {        \
     extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \
     WD_MLP_PACK();                                                                                    \
+    mlp_impl<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                            \
+  }                                                                                                   \
+  __global__ void __launch_bounds__(256, 1) HipPolicyMlpAct_##H1##x##H2##_k##KT1(WD_MLP_ACT_PARAMS) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \
+    WD_MLP_ACT_PACK();                                                                                \
     mlp_impl<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                            \
   }
 WD_MLP_KERNEL(256, 256, 1)
@@ -312,4 +370,52 @@ WD_MLP_KERNEL(128, 128, 3)
 WD_MLP_KERNEL(64, 64, 1)
 WD_MLP_KERNEL(64, 64, 2)
 WD_MLP_KERNEL(64, 64, 3)
+
+// HipRolloutRecord: the trainer's per-tick bookkeeping as ONE launch (it used to be ~20 framework kernels per tick:
+// index_select / index_copy_ per policy and array, the episodic-reward sums -- 100 us of the 670 us tick at
+// configs[2]).  After the env tick: row t (= *batch_row) of every policy's reward batch and of the done batch, the
+// running episodic reward per (replica, agent), and -- for replicas that finished on this tick -- the per-replica
+// sums the "Mean episodic reward" metric is made of (trainer_base.py:408-426, :514-601 keep the same quantities on
+// the host).  One block per replica.  `slot[a]` = policy * 65536 + index of agent a inside its policy.  The last
+// block to finish advances the batch row (every block has read it by then).
+__global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *__restrict__ done, int n_agents,
+                                 int n_envs, const int *__restrict__ slot, long long *batch_row, int *blocks_done,
+                                 int *done_batch, float *ep_count, float *reward_batch_a, float *ep_reward_a,
+                                 float *ep_sum_a, int n_pol_a, float *reward_batch_b, float *ep_reward_b,
+                                 float *ep_sum_b, int n_pol_b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rec_smem[];
+  float *const s_total = (float *)rec_smem;  // [n_agents] episodic reward of the agents of a replica that just finished
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const long long t = *batch_row;
+  const bool finished = done[e] > 0;
+  for (int a = tid; a < n_agents; a += blockDim.x) {
+    const int sl = slot[a], pol = sl >> 16, la = sl & 0xffff;
+    const int n_pol = pol ? n_pol_b : n_pol_a;
+    const float r = rewards[(long)e * n_agents + a];
+    (pol ? reward_batch_b : reward_batch_a)[((long)t * n_envs + e) * n_pol + la] = r;
+    float *const acc = (pol ? ep_reward_b : ep_reward_a) + (long)e * n_pol + la;
+    const float total = *acc + r;
+    *acc = finished ? 0.0f : total;
+    if (finished) s_total[a] = total;
+  }
+  if (tid == 0) done_batch[(long)t * n_envs + e] = done[e];
+  if (finished) {  // block-uniform, once per episode and replica
+    __syncthreads();
+    if (tid < 2 && (tid == 0 || n_pol_b > 0)) {  // thread p: policy p's agents, in agent order (deterministic sum)
+      float sum = 0.0f;
+      for (int a = 0; a < n_agents; ++a)
+        if ((slot[a] >> 16) == tid) sum += s_total[a];
+      (tid ? ep_sum_b : ep_sum_a)[e] += sum / (float)(tid ? n_pol_b : n_pol_a);
+    }
+    if (tid == 0) ep_count[e] += 1.0f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(blocks_done, 1) == (int)gridDim.x - 1) {
+      *blocks_done = 0;
+      *batch_row = t + 1;
+    }
+  }
+}
 }

@@ -126,6 +126,75 @@ class FusedPolicyForward:
         self.fn(*args, block=(64 * self.WAVES_PER_BLOCK, 1, 1), grid=grid, shared=self.lds_bytes)
 
 
+class FusedRolloutTick:
+    """The policy side of a rollout tick as TWO launches around the env's step (csrc/kernels/policy_mlp.hip):
+
+      forward()  HipPolicyMlpAct_*: the forward of ALL policies (one or two `FusedPolicyForward`s of the same shape) in
+                 one launch, the actions of both heads drawn in its epilogue -- same Philox counters and the same
+                 inverse-CDF search as the env's fused tick, on the probabilities the kernel would have written -- into
+                 the env's `sampled_actions` and row t of every policy's action batch; the observation rows into row t
+                 of the observation batches.  The probabilities never reach HBM.
+      (the env's `TickA` entry: step + reset of finished replicas on those actions -- RolloutEngine(presampled_actions=True))
+      record()   HipRolloutRecord: rewards / done into row t of the batches, the episodic-reward bookkeeping, t += 1.
+
+    `batch_row` is the device counter t (int64 [1]); everything is enqueued on torch's current stream and is free of
+    host-side indices, so a tick can be captured in a hipGraph."""
+
+    def __init__(self, function_manager, forwards, agent_ids, obs, actions, rewards, done, rng_state, stream_tag,
+                 batch_row, obs_batches, action_batches, reward_batches, done_batch, ep_rewards, ep_sums, ep_count):
+        assert 1 <= len(forwards) <= 2
+        f0 = forwards[0]
+        assert all((f.H, f.kt1, f.heads, f.F) == (f0.H, f0.kt1, f0.heads, f0.F) for f in forwards), \
+            "one launch serves policies of ONE network shape"
+        assert len(f0.heads) == 2, "the epilogue draws the two heads of a MultiDiscrete([A0, A1]) action"
+        E, N, F = obs.shape
+        assert obs.is_contiguous() and obs.dtype == torch.float32 and F == f0.F
+        assert actions.dtype == torch.int32 and actions.is_contiguous() and tuple(actions.shape) == (E, N, 2)
+        self.fwd_name = f"HipPolicyMlpAct_{f0.H}x{f0.H}_k{f0.kt1}"
+        function_manager.initialize_functions([self.fwd_name, "HipRolloutRecord"])
+        self.fwd, self.rec = function_manager.get_function(self.fwd_name), function_manager.get_function("HipRolloutRecord")
+        self.forwards, self.lds_bytes = forwards, f0.lds_bytes
+        dev, null = obs.device, np.uint64(0)
+        block_rows = f0.WAVES_PER_BLOCK * _WAVE_ROWS
+        slot = np.full(N, -1, dtype=np.int64)
+        per_policy, blocks = [], []
+        for k, (f, ids) in enumerate(zip(forwards, agent_ids)):
+            ids_host = np.asarray(ids.cpu().numpy(), dtype=np.int64)
+            slot[ids_host] = k * 65536 + np.arange(len(ids_host))
+            n_pol = len(ids_host)
+            contiguous = bool((np.diff(ids_host) == 1).all()) if n_pol > 1 else True
+            ids32 = ids.to(torch.int32).contiguous()
+            n_rows = E * n_pol
+            blocks.append((n_rows + block_rows - 1) // block_rows)
+            for t, shape in ((obs_batches[k], (E, n_pol, F)), (action_batches[k], (E, n_pol, 2)), (reward_batches[k], (E, n_pol))):
+                assert t.is_contiguous() and tuple(t.shape[1:]) == shape, (tuple(t.shape), shape)
+            assert action_batches[k].dtype == torch.int32
+            per_policy.append([null if contiguous else ids32, np.int32(ids_host[0]), np.int32(n_pol), np.int32(n_rows),
+                               *f.packed, obs_batches[k], action_batches[k]])
+            self._keep = getattr(self, "_keep", []) + [ids32]
+        assert (slot >= 0).all(), "every agent belongs to exactly one policy of the launch"
+        if len(forwards) == 1:
+            per_policy.append([null, np.int32(0), np.int32(1), np.int32(0)] + [null] * 8)
+        self.slot = torch.from_numpy(slot.astype(np.int32)).to(dev)
+        self.blocks_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.fwd_args = [obs, np.int32(F), np.int32(N), np.int32(f0.heads[0]), np.int32(f0.heads[1]), null, null, batch_row,
+                         rng_state, actions, np.int32(stream_tag), np.int32(blocks[0] if len(forwards) == 2 else 2 ** 30),
+                         *per_policy[0], *per_policy[1]]
+        self.fwd_grid, self.fwd_block = (sum(blocks), 1), (64 * f0.WAVES_PER_BLOCK, 1, 1)
+        second = len(forwards) == 2
+        self.rec_args = [rewards, done, np.int32(N), np.int32(E), self.slot, batch_row, self.blocks_done, done_batch, ep_count,
+                         reward_batches[0], ep_rewards[0], ep_sums[0], np.int32(per_policy[0][2]),
+                         reward_batches[1] if second else null, ep_rewards[1] if second else null,
+                         ep_sums[1] if second else null, np.int32(per_policy[1][2]) if second else np.int32(0)]
+        self.rec_grid, self.rec_block, self.rec_lds = (E, 1), (min(1024, (N + 63) // 64 * 64), 1, 1), 4 * N
+
+    def forward(self):
+        self.fwd(*self.fwd_args, block=self.fwd_block, grid=self.fwd_grid, shared=self.lds_bytes)
+
+    def record(self):
+        self.rec(*self.rec_args, block=self.rec_block, grid=self.rec_grid, shared=self.rec_lds)
+
+
 def rollout_policy_width(model, obs_size, widths=(32, 64)):
     """hidden width if `model` (training.models.FullyConnected) is a network the in-kernel rollout policies
     evaluate -- two hidden layers of equal width in `widths`, one action head -- else None"""
@@ -171,4 +240,5 @@ def pack_gridworld_policy(model, out=None):
         out = torch.zeros(n, dtype=torch.float32, device=w0.device)
     assert out.numel() == n
     out[: flat.numel()].copy_(flat)
+    out[flat.numel():].zero_()  # (the padding is never read)
     return out

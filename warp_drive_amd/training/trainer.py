@@ -31,7 +31,7 @@ from warp_drive_amd.training.data_loader import create_and_push_data_placeholder
 from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
-from warp_drive_amd.training.policy_kernel import (FusedPolicyForward, pack_gridworld_policy, pack_rollout_policy,
+from warp_drive_amd.training.policy_kernel import (FusedPolicyForward, FusedRolloutTick, pack_gridworld_policy, pack_rollout_policy,
                                                     rollout_policy_width)
 from warp_drive_amd.utils.constants import Constants
 
@@ -180,8 +180,9 @@ class Trainer:
         }
         # episodic reward bookkeeping, all on the device
         self._ep_reward = {p: torch.zeros((E, len(self.policy_map[p])), device=self.device) for p in self.policies}
-        self._ep_sum = {p: torch.zeros((), device=self.device) for p in self.policies}
-        self._ep_cnt = torch.zeros((), device=self.device)
+        # (per replica: summed over the replicas when a metric is read; the record kernel accumulates them in place)
+        self._ep_sum = {p: torch.zeros(E, device=self.device) for p in self.policies}
+        self._ep_cnt = torch.zeros(E, device=self.device)
         self.perf_stats = PerfStats()
         self.metrics = {}
         # rollout tick as a hipGraph: needs a single-launch env tick (no Python-side branching)
@@ -206,6 +207,27 @@ class Trainer:
                         and rows >= int(tcfg.get("fused_policy_forward_min_rows", 0))):
                     self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size)
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
+        # ---- the whole tick in THREE launches (`trainer.fused_tick`, default on): every policy's forward in one launch
+        # with the actions drawn in its epilogue, the env's step + reset on those actions, the bookkeeping
+        # (training/policy_kernel.py::FusedRolloutTick).  Needs: every policy on the fused forward with one network
+        # shape, a two-head action space, and an env with a step + reset entry for given actions.
+        self._fast_tick = None
+        fw = [self._fused_forward[pol] for pol in self.policies]
+        if (bool(tcfg.get("fused_tick", True)) and all(f is not None for f in fw) and len(fw) <= 2 and self.engine.fused
+                and len(self.head_sizes) == 2 and self.batch_len > 1 and self.actions.dtype == torch.int32
+                and getattr(env_wrapper.env, "has_presampled_tick", lambda: False)()
+                and all((f.H, f.kt1, f.heads) == (fw[0].H, fw[0].kt1, fw[0].heads) for f in fw)):
+            from warp_drive_amd.managers.function_manager import _stream_tag
+
+            self._fast_tick = FusedRolloutTick(
+                env_wrapper.cuda_function_manager, fw, [self.ids[pol] for pol in self.policies],
+                self.obs.reshape(E, N, -1), self.actions, self.rewards, self.done, self.sampler.rng_state,
+                _stream_tag("tick"), self._b_idx, [self.batch[pol]["obs"] for pol in self.policies],
+                [self.batch[pol]["actions"] for pol in self.policies], [self.batch[pol]["rewards"] for pol in self.policies],
+                self.done_batch, [self._ep_reward[pol] for pol in self.policies],
+                [self._ep_sum[pol] for pol in self.policies], self._ep_cnt)
+            self._presampled_engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
+                                                    presampled_actions=True)
         # ---- whole-batch rollout in ONE launch: envs whose tick kernel can evaluate small policies itself (Cartpole:
         # csrc/kernels/cartpole.hip; TagGridWorld with 5 agents and full observations: tag_gridworld_n5.hip -- two hidden
         # layers of 32 / 64 units, one head) run all `batch_len` ticks of a training batch -- policy forward, sampling,
@@ -278,6 +300,11 @@ class Trainer:
         """One rollout tick, entirely on the device and free of host-side indices: policy forward ->
         fused env tick -> batch bookkeeping at row `self._b_idx` (a device counter), so the same
         sequence of launches can be replayed from a hipGraph."""
+        if self._fast_tick is not None:
+            self._fast_tick.forward()         # all policies: forward + the actions of both heads + batch rows (obs, actions)
+            self._presampled_engine.run(1)    # the env's step + reset of finished replicas on those actions
+            self._fast_tick.record()          # rewards / done rows, episodic sums, batch row += 1
+            return
         b = self._b_idx
         flat_obs = self.obs.reshape(self.num_envs, self.w.n_agents, -1)
         for pol in self.policies:
@@ -306,9 +333,9 @@ class Trainer:
             self.batch[pol]["actions"].index_copy_(0, b, a.unsqueeze(0))
             self.batch[pol]["rewards"].index_copy_(0, b, r.unsqueeze(0))
             self._ep_reward[pol] += r
-            self._ep_sum[pol] += (self._ep_reward[pol].mean(dim=1) * finished).sum()
+            self._ep_sum[pol] += self._ep_reward[pol].mean(dim=1) * finished
             self._ep_reward[pol] *= (1.0 - finished)[:, None]
-        self._ep_cnt += finished.sum()
+        self._ep_cnt += finished
         b += 1
 
     def _capture_tick_graph(self):
@@ -359,10 +386,10 @@ class Trainer:
             base = torch.gather(total, 0, prev.clamp(min=0)[..., None].expand_as(total))
             base = torch.where((prev >= 0)[..., None], base, torch.zeros_like(base))
             episode = total - base                                   # reward of the running episode up to tick t
-            self._ep_sum[pol] += (episode.mean(dim=2) * d).sum()
+            self._ep_sum[pol] += (episode.mean(dim=2) * d).sum(dim=0)
             carried = torch.gather(total, 0, end.clamp(min=0)[None, :, None].expand(1, *total.shape[1:]))[0]
             self._ep_reward[pol] = torch.where((end >= 0)[:, None], total[-1] - carried, total[-1])
-        self._ep_cnt += d.sum()
+        self._ep_cnt += d.sum(dim=0)
 
     def _generate_rollout_batch(self):
         if self._batch_rollout is not None:
@@ -412,8 +439,8 @@ class Trainer:
                 m = metrics[pol]
                 m["Current timestep"] = self.current_timestep[pol]
                 m["Learning rate"] = pcfg["lr"]
-                cnt = float(self._ep_cnt.item())
-                m["Mean episodic reward"] = float(self._ep_sum[pol].item()) / cnt if cnt > 0 else float("nan")
+                cnt = float(self._ep_cnt.sum().item())
+                m["Mean episodic reward"] = float(self._ep_sum[pol].sum().item()) / cnt if cnt > 0 else float("nan")
         return metrics
 
     # ----------------------------------------------------------------------------- train
