@@ -322,7 +322,7 @@ def test_three_launch_tick_equals_the_per_op_tick(tmp_path):
     from warp_drive_amd.training.scripts.train import setup_trainer
 
     require_gpu()
-    ov = {"trainer": {"num_envs": 37, "train_batch_size": 37 * 12, "num_episodes": 40, "seed": 11,
+    ov = {"trainer": {"num_envs": 37, "train_batch_size": 37 * 12, "num_episodes": 4000, "seed": 11,
                       "fused_policy_forward_min_rows": 0},
           "env": {"num_runners": 59, "episode_length": 9, "num_other_agents_observed": 10},
           "saving": {"metrics_log_freq": 100, "model_params_save_freq": 0}}
