@@ -29,7 +29,8 @@ def _fm():
     (64, 4, [2], 300, 1, [0]),                                      # Cartpole-like: tiny rows, tiny head
     (256, 96, [30, 33], 9, 4, [3, 1]),                              # widest supported row, 64 output rows, ids out of order
 ])
-def test_fused_forward_matches_torch(hidden, F, heads, E, N, ids):
+@pytest.mark.parametrize("arithmetic", ["float32", "bf16x3"])
+def test_fused_forward_matches_torch(hidden, F, heads, E, N, ids, arithmetic):
     from warp_drive_amd.training.models import FullyConnected
     from warp_drive_amd.training.policy_kernel import FusedPolicyForward
 
@@ -40,7 +41,7 @@ def test_fused_forward_matches_torch(hidden, F, heads, E, N, ids):
         for p in model.parameters():
             p.mul_(3.0) if p.dim() == 2 else p.normal_(0.0, 0.5)
     assert FusedPolicyForward.supports(model, F)
-    fused = FusedPolicyForward(_fm(), model, F)
+    fused = FusedPolicyForward(_fm(), model, F, arithmetic=arithmetic)  # (the SAME gates for both arithmetics)
     obs = torch.randn(E, N, F, device=dev)
     ids_t = torch.tensor(ids, dtype=torch.int32, device=dev)
     n_pol = len(ids)

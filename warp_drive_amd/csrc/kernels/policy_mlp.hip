@@ -124,98 +124,11 @@ struct MlpArgs {
   int tile0;              // first 32-row tile of THIS policy in the launch (several policies share one launch)
 };
 
-// TN1 / TN2: hidden widths / 32; KT1: ceil(F / 32)
-template <int TN1, int TN2, int KT1>
-__device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
-  constexpr int TN3 = 2;  // output rows padded to 64: all head logits + the value
-  constexpr int CHUNK = (TN1 > TN2 ? TN1 : TN2) * 1024;  // floats per LDS buffer
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
-  float *const buf0 = lds, *const buf1 = lds + CHUNK;
-  const int g = ((int)(blockIdx.x * (blockDim.x >> 6) + wave) - p.tile0) * 32 + j;  // policy-local row of this lane's column
-  const bool valid = g < p.n_rows;
-  const int gc = valid ? g : p.n_rows - 1;
-  const int env = gc / p.n_pol, a = gc - env * p.n_pol;
-  const long src_row = (long)env * p.N + (p.agent_ids ? p.agent_ids[a] : p.id0 + a);
-
-  // first weight chunk, then this lane's part of its observation row: features
-  // [32 kt + 16 h, 32 kt + 16 h + 16) of k-tile kt (zero past the end of the row)
-  mlp_fetch(buf0, p.w1, TN1, wave, lane);
-  mlp_v16 feat[KT1];
-  {
-    const float *row = p.obs + src_row * p.F;
-    float *out = nullptr;
-    if (p.obs_out && valid) {
-      const long long t = p.batch_row ? *p.batch_row : 0;
-      out = p.obs_out + ((long)t * p.n_rows + g) * p.F;
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT1; ++kt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f0 = 32 * kt + 16 * h + 4 * q;
-        mlp_v4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (f0 + 4 <= p.F) {
-          v = *(const mlp_v4u *)(row + f0);
-          if (out) *(mlp_v4u *)(out + f0) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (f0 + e < p.F) {
-              v[e] = row[f0 + e];
-              if (out) out[f0 + e] = v[e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) feat[kt][4 * q + e] = v[e];
-      }
-  }
-
-  // chunk c of the stream lives in buf[c & 1]; while it is consumed the next one is fetched.  The
-  // fetch instructions come AFTER the first quarter of the chunk's MFMAs: at a chunk boundary the
-  // matrix pipe has nothing queued, so whatever is issued before the first MFMA is dead time
-  // (stamped build: ~1 200 cycles per boundary with the fetch first, 19 boundaries per block).
-  int c = 0;
-#define MLP_CHUNK(TN, acc, bfrag, next_src, next_tiles, have_next)                          \
-  {                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's part of chunk c */  \
-    __syncthreads(); /* everybody's part; and nobody reads the other buffer any more */     \
-    const float *const cur = (c & 1) ? buf1 : buf0;                                         \
-    mlp_ktile<TN, 0, 1>(acc, cur, bfrag, lane);                                             \
-    if (have_next) mlp_fetch((c & 1) ? buf0 : buf1, (next_src), (next_tiles), wave, lane);  \
-    mlp_ktile<TN, 1, 4>(acc, cur, bfrag, lane);                                             \
-    ++c;                                                                                    \
-  }
-
-  // ---- layer 1: H1^T = relu(W1 . X^T + b1)
-  // (every layer's accumulators start from its bias; the loads are issued a layer ahead so that
-  // nobody waits for them -- one wavefront per SIMD has nothing else to run meanwhile)
-  mlp_v16 acc1[TN1], acc2[TN2], acc3[TN3];
-  mlp_init<TN1>(acc1, p.b1, h);
-  mlp_init<TN2>(acc2, p.b2, h);
-#pragma unroll
-  for (int kt = 0; kt < KT1; ++kt) {
-    const bool last = kt == KT1 - 1;
-    MLP_CHUNK(TN1, acc1, feat[kt], last ? p.w2 : p.w1 + (size_t)(kt + 1) * TN1 * 1024, last ? TN2 : TN1, true)
-  }
-  mlp_relu<TN1>(acc1);
-
-  // ---- layer 2: H2^T = relu(W2 . H1^T + b2)
-  mlp_init<TN3>(acc3, p.b3, h);
-#pragma unroll
-  for (int kt = 0; kt < TN1; ++kt) {
-    const bool last = kt == TN1 - 1;
-    MLP_CHUNK(TN2, acc2, acc1[kt], last ? p.w3 : p.w2 + (size_t)(kt + 1) * TN2 * 1024, last ? TN3 : TN2, true)
-  }
-  mlp_relu<TN2>(acc2);
-
-  // ---- output layer: logits^T (and the value) = W3 . H2^T + b3
-#pragma unroll
-  for (int kt = 0; kt < TN2; ++kt) {
-    const bool last = kt == TN2 - 1;
-    MLP_CHUNK(TN3, acc3, acc2[kt], p.w3 + (size_t)(kt + 1) * TN3 * 1024, TN3, !last)
-  }
-#undef MLP_CHUNK
-
+// ---- what follows the output layer, shared by both arithmetic paths: softmax per head, the actions drawn from the
+// LDS tile (when asked for), probabilities / value to HBM (when asked for).  acc3: the logits^T tiles (+ the value).
+template <int TN3>
+__device__ __forceinline__ void mlp_epilogue(const MlpArgs &p, float *lds, mlp_v16 (&acc3)[TN3], int g, bool valid,
+                                             long src_row, int wave, int lane, int j, int h) {
   // ---- softmax per head over the rows of a column: a lane holds half of the rows, its partner
   // (lane ^ 32) the other half.  Straight-line code (selects, exp for every register): with one
   // wavefront per SIMD every skipped-over branch costs as much as the work it skips.
@@ -309,6 +222,293 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
   if (valid && p.values && ((r2 >> 2) & 1) == h && r2 < 32 * TN3) p.values[g] = value;
 }
 
+// TN1 / TN2: hidden widths / 32; KT1: ceil(F / 32)
+template <int TN1, int TN2, int KT1>
+__device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
+  constexpr int TN3 = 2;  // output rows padded to 64: all head logits + the value
+  constexpr int CHUNK = (TN1 > TN2 ? TN1 : TN2) * 1024;  // floats per LDS buffer
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  float *const buf0 = lds, *const buf1 = lds + CHUNK;
+  const int g = ((int)(blockIdx.x * (blockDim.x >> 6) + wave) - p.tile0) * 32 + j;  // policy-local row of this lane's column
+  const bool valid = g < p.n_rows;
+  const int gc = valid ? g : p.n_rows - 1;
+  const int env = gc / p.n_pol, a = gc - env * p.n_pol;
+  const long src_row = (long)env * p.N + (p.agent_ids ? p.agent_ids[a] : p.id0 + a);
+
+  // first weight chunk, then this lane's part of its observation row: features
+  // [32 kt + 16 h, 32 kt + 16 h + 16) of k-tile kt (zero past the end of the row)
+  mlp_fetch(buf0, p.w1, TN1, wave, lane);
+  mlp_v16 feat[KT1];
+  {
+    const float *row = p.obs + src_row * p.F;
+    float *out = nullptr;
+    if (p.obs_out && valid) {
+      const long long t = p.batch_row ? *p.batch_row : 0;
+      out = p.obs_out + ((long)t * p.n_rows + g) * p.F;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * kt + 16 * h + 4 * q;
+        mlp_v4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (f0 + 4 <= p.F) {
+          v = *(const mlp_v4u *)(row + f0);
+          if (out) *(mlp_v4u *)(out + f0) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (f0 + e < p.F) {
+              v[e] = row[f0 + e];
+              if (out) out[f0 + e] = v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) feat[kt][4 * q + e] = v[e];
+      }
+  }
+
+  // chunk c of the stream lives in buf[c & 1]; while it is consumed the next one is fetched.  The
+  // fetch instructions come AFTER the first quarter of the chunk's MFMAs: at a chunk boundary the
+  // matrix pipe has nothing queued, so whatever is issued before the first MFMA is dead time
+  // (stamped build: ~1 200 cycles per boundary with the fetch first, 19 boundaries per block).
+  int c = 0;
+#define MLP_CHUNK(TN, acc, bfrag, next_src, next_tiles, have_next)                          \
+  {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's part of chunk c */  \
+    __syncthreads(); /* everybody's part; and nobody reads the other buffer any more */     \
+    const float *const cur = (c & 1) ? buf1 : buf0;                                         \
+    mlp_ktile<TN, 0, 1>(acc, cur, bfrag, lane);                                             \
+    if (have_next) mlp_fetch((c & 1) ? buf0 : buf1, (next_src), (next_tiles), wave, lane);  \
+    mlp_ktile<TN, 1, 4>(acc, cur, bfrag, lane);                                             \
+    ++c;                                                                                    \
+  }
+
+  // ---- layer 1: H1^T = relu(W1 . X^T + b1)
+  // (every layer's accumulators start from its bias; the loads are issued a layer ahead so that
+  // nobody waits for them -- one wavefront per SIMD has nothing else to run meanwhile)
+  mlp_v16 acc1[TN1], acc2[TN2], acc3[TN3];
+  mlp_init<TN1>(acc1, p.b1, h);
+  mlp_init<TN2>(acc2, p.b2, h);
+#pragma unroll
+  for (int kt = 0; kt < KT1; ++kt) {
+    const bool last = kt == KT1 - 1;
+    MLP_CHUNK(TN1, acc1, feat[kt], last ? p.w2 : p.w1 + (size_t)(kt + 1) * TN1 * 1024, last ? TN2 : TN1, true)
+  }
+  mlp_relu<TN1>(acc1);
+
+  // ---- layer 2: H2^T = relu(W2 . H1^T + b2)
+  mlp_init<TN3>(acc3, p.b3, h);
+#pragma unroll
+  for (int kt = 0; kt < TN1; ++kt) {
+    const bool last = kt == TN1 - 1;
+    MLP_CHUNK(TN2, acc2, acc1[kt], last ? p.w3 : p.w2 + (size_t)(kt + 1) * TN2 * 1024, last ? TN3 : TN2, true)
+  }
+  mlp_relu<TN2>(acc2);
+
+  // ---- output layer: logits^T (and the value) = W3 . H2^T + b3
+#pragma unroll
+  for (int kt = 0; kt < TN2; ++kt) {
+    const bool last = kt == TN2 - 1;
+    MLP_CHUNK(TN3, acc3, acc2[kt], p.w3 + (size_t)(kt + 1) * TN3 * 1024, TN3, !last)
+  }
+#undef MLP_CHUNK
+
+  mlp_epilogue<TN3>(p, lds, acc3, g, valid, src_row, wave, lane, j, h);
+}
+
+// =====================================================================================================================
+//   bf16x3: the same network with every float32 product emulated on the bf16 matrix cores (`trainer.policy_arithmetic`)
+// =====================================================================================================================
+// v_mfma_f32_32x32x2_f32 runs at the float32 VECTOR rate: 1/16 of the bf16 matrix rate (MI355X_MICROARCH.md).  Every
+// float32 x is split EXACTLY into three bf16 terms, x = x_hi + x_mid + x_lo (+ a residual below 2^-24 |x|: each term is
+// the round-to-nearest bf16 of what the previous ones left, and those subtractions are exact in float32), and a product
+// w . x is the sum of the six partial products that reach 2^-24 of it:
+//     w_hi x_hi + (w_hi x_mid + w_mid x_hi) + (w_mid x_mid + w_hi x_lo + w_lo x_hi)        [dropped: <= 2^-24 |w x| each]
+// each exact in float32 (8 x 8 significant bits), accumulated in float32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32
+// cycles cover 16 contraction indices where the float32 form needs 8 of 64 cycles -- 2.7 x the rate for an error of
+// the size of float32 rounding itself.  NOT bit-identical to the float32-MFMA path (neither is that one to the
+// framework's GEMMs: summation order); the gates are the same: probabilities within 2e-6 of the PyTorch network
+// (tests/test_gpu_policy_kernel.py), sampled actions draw for draw on those probabilities.
+// The weights are split once per optimizer step on the host (training/policy_kernel.py::pack, [kt][term][tile][k half]
+// [lane][8 bf16]: 6 KB per 32 x 32 tile and k-tile); the activations in registers after every layer's ReLU
+// (v_cvt_pk_bf16_f32: ~5.5 VALU instructions per value, 128 values per lane and layer).
+//
+// Weight stream: THREE LDS buffers of one k-tile and the hand-over barrier in the MIDDLE of a chunk's MFMAs.  With two
+// buffers the barrier sits at the chunk boundary, where the matrix pipe has nothing queued -- ~1 000 cycles of dead
+// time, 19 times per block (float32 path, stamped) -- and it would weigh three times as much against MFMAs that take
+// a third of the time.  Here, inside chunk c: first group of MFMAs; wait for this wavefront's pieces of chunk c + 1
+// (issued a whole chunk earlier); barrier = chunk c + 1 is published AND every wavefront has left chunk c - 1, so its
+// buffer takes the fetch of chunk c + 2, issued right there; remaining MFMAs, whose operands were read from LDS before
+// the barrier.  A chunk boundary is then just the next LDS read.
+typedef __bf16 mlp_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mlp_bf2 __attribute__((ext_vector_type(2)));
+typedef float mlp_f2 __attribute__((ext_vector_type(2)));
+
+// x[0 .. 15] -> out[term][k half] (8 bf16 each): element e of half q is x[8 q + e]
+__device__ __forceinline__ void mlp_split3(const mlp_v16 &x, mlp_bf8 (&out)[3][2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const mlp_f2 v = {x[8 * q + e], x[8 * q + e + 1]};
+      const mlp_bf2 hi = __builtin_convertvector(v, mlp_bf2);
+      const mlp_f2 r1 = v - __builtin_convertvector(hi, mlp_f2);    // exact
+      const mlp_bf2 mid = __builtin_convertvector(r1, mlp_bf2);
+      const mlp_f2 r2 = r1 - __builtin_convertvector(mid, mlp_f2);  // exact
+      const mlp_bf2 lo = __builtin_convertvector(r2, mlp_bf2);
+      out[0][q][e] = hi[0]; out[0][q][e + 1] = hi[1];
+      out[1][q][e] = mid[0]; out[1][q][e + 1] = mid[1];
+      out[2][q][e] = lo[0]; out[2][q][e + 1] = lo[1];
+    }
+}
+
+// `pieces` KB of packed weights global -> LDS, this wavefront's share (1 KB per instruction)
+__device__ __forceinline__ void mlp_fetch_kb(float *buf, const float *src, int pieces, int wave, int lane) {
+  const int rounds = pieces / (int)(blockDim.x >> 6);
+  for (int r = 0; r < rounds; ++r) {
+    const int v0 = (wave * rounds + r) * 64;  // first 16-byte vector of this instruction (wave-uniform)
+    __builtin_amdgcn_global_load_lds(WD_GLOBAL_PTR(src + 4 * (v0 + lane)), WD_LDS_PTR(buf + 4 * v0), 16, 0, 0);
+  }
+}
+
+// One chunk = one k-tile (32 contraction indices) of a layer with TN output tiles: acc[tn] += W_chunk[tn] . B, B = the
+// three-term split `b` of this k-tile's activations.  Output tiles in PAIRS (MFMAs alternate between two accumulators:
+// an instruction between two MFMAs on the same accumulator costs ~43 cycles, between different ones ~6); the LDS
+// operand reads of the next pair are issued before the MFMAs of the current one.  `sync` runs after the first pair.
+template <int TN, typename Sync>
+__device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *buf, const mlp_bf8 (&b)[3][2], int lane,
+                                              Sync sync) {
+  constexpr int G = TN < 2 ? 1 : 2, NG = TN / G;
+  const mlp_bf8 *const w = (const mlp_bf8 *)buf;  // [term][tn][k half][lane]
+  mlp_bf8 a[2][G][3][2];
+#define MLP3_READ(gi_)                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < G; ++t)                                                         \
+  _Pragma("unroll") for (int term = 0; term < 3; ++term)                                                \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                         \
+      a[(gi_) & 1][t][term][q] = w[((term * TN + (gi_) * G + t) * 2 + q) * 64 + lane];
+  MLP3_READ(0)
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    if (gi + 1 < NG) MLP3_READ(gi + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    // (w term, x term) in ascending size of the partial product: lo x hi, hi x lo, mid x mid, mid x hi, hi x mid, hi x hi
+    constexpr int WT[6] = {2, 0, 1, 1, 0, 0}, XT[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+          acc[gi * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][t][WT[m]][q], b[XT[m]][q], acc[gi * G + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (gi == 0) sync();
+  }
+#undef MLP3_READ
+}
+
+template <int TN1, int TN2, int KT1>
+__device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
+  constexpr int TN3 = 2;
+  constexpr int TNMAX = TN1 > TN2 ? TN1 : TN2;
+  constexpr int CHUNK = TNMAX * 1536;  // floats per LDS buffer: 6 KB per output tile
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int g = ((int)(blockIdx.x * (blockDim.x >> 6) + wave) - p.tile0) * 32 + j;
+  const bool valid = g < p.n_rows;
+  const int gc = valid ? g : p.n_rows - 1;
+  const int env = gc / p.n_pol, ag = gc - env * p.n_pol;
+  const long src_row = (long)env * p.N + (p.agent_ids ? p.agent_ids[ag] : p.id0 + ag);
+
+  // the chunk stream: KT1 k-tiles of layer 1, TN1 of layer 2, TN2 of the output layer; chunk c lives in buffer c % 3
+  constexpr int NC = KT1 + TN1 + TN2;
+  int c = 0;  // (compile-time after unrolling)
+  auto chunk_src = [&](int cc) -> const float * {
+    return cc < KT1 ? p.w1 + (size_t)cc * TN1 * 1536
+                    : cc < KT1 + TN1 ? p.w2 + (size_t)(cc - KT1) * TN2 * 1536 : p.w3 + (size_t)(cc - KT1 - TN1) * TN3 * 1536;
+  };
+  auto chunk_pieces = [&](int cc) -> int { return 6 * (cc < KT1 ? TN1 : cc < KT1 + TN1 ? TN2 : TN3); };
+  auto buffer = [&](int cc) -> float * { return lds + (cc % 3) * CHUNK; };
+
+  mlp_fetch_kb(buffer(0), chunk_src(0), chunk_pieces(0), wave, lane);
+  // this lane's part of its observation row: k-tile kt, k half q: features [32 kt + 16 q + 8 h, + 8)
+  mlp_bf8 x1[KT1][3][2];
+  {
+    const float *row = p.obs + src_row * p.F;
+    float *out = nullptr;
+    if (p.obs_out && valid) {
+      const long long t = p.batch_row ? *p.batch_row : 0;
+      out = p.obs_out + ((long)t * p.n_rows + g) * p.F;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+      mlp_v16 feat;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {
+          const int f0 = 32 * kt + 16 * q + 8 * h + 4 * e4;
+          mlp_v4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (f0 + 4 <= p.F) {
+            v = *(const mlp_v4u *)(row + f0);
+            if (out) *(mlp_v4u *)(out + f0) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (f0 + e < p.F) {
+                v[e] = row[f0 + e];
+                if (out) out[f0 + e] = v[e];
+              }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) feat[8 * q + 4 * e4 + e] = v[e];
+        }
+      mlp_split3(feat, x1[kt]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of chunk 0 (and its row)
+  __syncthreads();                                   // chunk 0 is published
+  if (NC > 1) mlp_fetch_kb(buffer(1), chunk_src(1), chunk_pieces(1), wave, lane);
+
+  // inside chunk c, after its first MFMAs (see the header): publish chunk c + 1, fetch chunk c + 2
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 2 < NC) mlp_fetch_kb(buffer(c + 2), chunk_src(c + 2), chunk_pieces(c + 2), wave, lane);
+  };
+
+  mlp_v16 acc1[TN1], acc2[TN2], acc3[TN3];
+  // ---- layer 1
+  mlp_init<TN1>(acc1, p.b1, h);
+#pragma unroll
+  for (int kt = 0; kt < KT1; ++kt) {
+    mlp_chunk_bx3<TN1>(acc1, buffer(c), x1[kt], lane, sync);
+    ++c;
+  }
+  mlp_relu<TN1>(acc1);
+  mlp_bf8 x2[TN1][3][2];
+#pragma unroll
+  for (int t = 0; t < TN1; ++t) mlp_split3(acc1[t], x2[t]);
+  // ---- layer 2
+  mlp_init<TN2>(acc2, p.b2, h);
+#pragma unroll
+  for (int kt = 0; kt < TN1; ++kt) {
+    mlp_chunk_bx3<TN2>(acc2, buffer(c), x2[kt], lane, sync);
+    ++c;
+  }
+  mlp_relu<TN2>(acc2);
+  mlp_bf8 x3[TN2][3][2];
+#pragma unroll
+  for (int t = 0; t < TN2; ++t) mlp_split3(acc2[t], x3[t]);
+  // ---- output layer
+  mlp_init<TN3>(acc3, p.b3, h);
+#pragma unroll
+  for (int kt = 0; kt < TN2; ++kt) {
+    mlp_chunk_bx3<TN3>(acc3, buffer(c), x3[kt], lane, sync);
+    ++c;
+  }
+  mlp_epilogue<TN3>(p, lds, acc3, g, valid, src_row, wave, lane, j, h);
+}
+
 }  // namespace
 
 #define WD_MLP_PARAMS                                                                                 \
@@ -360,6 +560,18 @@ extern "C" {
     extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \
     WD_MLP_ACT_PACK();                                                                                \
     mlp_impl<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                            \
+  }                                                                                                   \
+  /* the bf16x3 arithmetic: same arguments, weights packed as three bf16 terms, dynamic LDS = 3 buffers */ \
+  /* of max(H1, H2) / 32 * 6144 bytes                                                                 */ \
+  __global__ void __launch_bounds__(256, 1) HipPolicyMlpBx3_##H1##x##H2##_k##KT1(WD_MLP_PARAMS) {     \
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \
+    WD_MLP_PACK();                                                                                    \
+    mlp_impl_bx3<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                        \
+  }                                                                                                   \
+  __global__ void __launch_bounds__(256, 1) HipPolicyMlpActBx3_##H1##x##H2##_k##KT1(WD_MLP_ACT_PARAMS) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                          \
+    WD_MLP_ACT_PACK();                                                                                \
+    mlp_impl_bx3<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                        \
   }
 WD_MLP_KERNEL(256, 256, 1)
 WD_MLP_KERNEL(256, 256, 2)

@@ -35,6 +35,30 @@ def _pack_indices(n_out_tiles, n_k_tiles, first_layer):
     return rows, cols
 
 
+def _pack_indices_bx3(n_out_tiles, n_k_tiles, first_layer):
+    """(row, col) gather indices of ONE term of the bf16x3 weight tensor [KT, (3,) TN, 2, 64, 8]: lane l supplies
+    A[i = l & 31][k = 8 (l >> 5) + e] of a 32x32x16 MFMA; k half q of the first layer contracts features
+    32 kt + 16 q + 8 h + e, of the later layers the rows (32 kt + row_of(8 q + e, h)) the previous layer's accumulators
+    hold in register 8 q + e."""
+    kt, tn, q, lane, e = np.meshgrid(np.arange(n_k_tiles), np.arange(n_out_tiles), np.arange(2), np.arange(64),
+                                     np.arange(8), indexing="ij")
+    h = lane >> 5
+    rows = tn * 32 + (lane & 31)
+    cols = 32 * kt + (16 * q + 8 * h + e if first_layer else _row_of(8 * q + e, h))
+    return rows, cols
+
+
+def split_bf16x3(w):
+    """float32 tensor -> [3, ...] bfloat16 terms hi, mid, lo with hi + mid + lo = w up to 2^-24 |w| (each term is the
+    round-to-nearest bf16 of what the previous ones left; the subtractions are exact in float32)"""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo])
+
+
 def _bias_indices(n_tiles):
     tn, h, s = np.meshgrid(np.arange(n_tiles), np.arange(2), np.arange(16), indexing="ij")
     return tn * 32 + _row_of(s, h)
@@ -55,24 +79,35 @@ class FusedPolicyForward:
         return (h1 == h2 and h1 in cls.HIDDEN and 1 <= obs_size <= cls.MAX_OBS and 1 <= len(heads) <= 2
                 and sum(heads) + 1 <= 32 * _OUT_TILES and fc["0"][0].in_features == obs_size)
 
-    def __init__(self, function_manager, model, obs_size):
+    ARITHMETICS = ("float32", "bf16x3")
+
+    def __init__(self, function_manager, model, obs_size, arithmetic="float32"):
+        """arithmetic: "float32" = v_mfma_f32_32x32x2_f32 (an fmaf chain); "bf16x3" = every float32 product as six bf16
+        partial products on the bf16 matrix cores (2.7 x the matrix rate, error of the size of float32 rounding: see
+        csrc/kernels/policy_mlp.hip) -- same gates, same interface."""
         assert self.supports(model, obs_size), "unsupported policy shape for the fused forward"
+        assert arithmetic in self.ARITHMETICS
         self.model = model
+        self.arithmetic = arithmetic
+        self.bx3 = arithmetic == "bf16x3"
+        self.kernel_tag = "Bx3" if self.bx3 else ""
         self.F = int(obs_size)
         self.H = model.fc["0"][0].out_features
         self.kt1 = (self.F + 31) // 32
         self.heads = [int(a) for a in model.head_sizes]
-        name = f"HipPolicyMlp_{self.H}x{self.H}_k{self.kt1}"
+        name = f"HipPolicyMlp{self.kernel_tag}_{self.H}x{self.H}_k{self.kt1}"
         function_manager.initialize_functions([name])
         self.fn = function_manager.get_function(name)
-        # two weight buffers of one k-tile; reused at the end for one [32][65] output tile (+32 row ids) per wavefront
-        self.lds_bytes = max(2 * (self.H // 32) * 4096, 4 * (32 * 65 + 32) * 4)
+        # float32: two weight buffers of one k-tile (4 KB per output tile); bf16x3: three (6 KB per output tile); reused
+        # at the end for one [32][65] output tile (+32 row ids) per wavefront
+        self.lds_bytes = max((3 * 6144 if self.bx3 else 2 * 4096) * (self.H // 32), 4 * (32 * 65 + 32) * 4)
         dev = next(model.parameters()).device
         tn = self.H // 32
         as_idx = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self._idx = [tuple(as_idx(x) for x in _pack_indices(tn, self.kt1, True)),
-                     tuple(as_idx(x) for x in _pack_indices(tn, tn, False)),
-                     tuple(as_idx(x) for x in _pack_indices(_OUT_TILES, tn, False))]
+        indices = _pack_indices_bx3 if self.bx3 else _pack_indices
+        self._idx = [tuple(as_idx(x) for x in indices(tn, self.kt1, True)),
+                     tuple(as_idx(x) for x in indices(tn, tn, False)),
+                     tuple(as_idx(x) for x in indices(_OUT_TILES, tn, False))]
         self._bidx = [as_idx(_bias_indices(tn)), as_idx(_bias_indices(tn)), as_idx(_bias_indices(_OUT_TILES))]
         self._pads = [(tn * 32, self.kt1 * 32), (tn * 32, tn * 32), (_OUT_TILES * 32, tn * 32)]
         self.packed = None
@@ -91,7 +126,11 @@ class FusedPolicyForward:
             wp[:w.shape[0], :w.shape[1]] = w.detach().float()
             bp = torch.zeros((pr,), dtype=torch.float32, device=w.device)
             bp[:b.shape[0]] = b.detach().float()
-            packed += [wp[rows, cols].contiguous(), bp[bidx].contiguous()]
+            if self.bx3:  # [KT, 3 terms, TN, 2 k halves, 64 lanes, 8] bfloat16
+                wpk = split_bf16x3(wp)[:, rows, cols].transpose(0, 1).contiguous()
+            else:         # [KT, TN, 4, 64 lanes, 4] float32
+                wpk = wp[rows, cols].contiguous()
+            packed += [wpk, bp[bidx].contiguous()]
         if self.packed is None:
             self.packed = packed
         else:  # in place: a captured hipGraph of the rollout tick keeps reading the same addresses
@@ -150,7 +189,8 @@ class FusedRolloutTick:
         E, N, F = obs.shape
         assert obs.is_contiguous() and obs.dtype == torch.float32 and F == f0.F
         assert actions.dtype == torch.int32 and actions.is_contiguous() and tuple(actions.shape) == (E, N, 2)
-        self.fwd_name = f"HipPolicyMlpAct_{f0.H}x{f0.H}_k{f0.kt1}"
+        assert all(f.arithmetic == f0.arithmetic for f in forwards)
+        self.fwd_name = f"HipPolicyMlpAct{f0.kernel_tag}_{f0.H}x{f0.H}_k{f0.kt1}"
         function_manager.initialize_functions([self.fwd_name, "HipRolloutRecord"])
         self.fwd, self.rec = function_manager.get_function(self.fwd_name), function_manager.get_function("HipRolloutRecord")
         self.forwards, self.lds_bytes = forwards, f0.lds_bytes

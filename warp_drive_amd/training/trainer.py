@@ -205,7 +205,8 @@ class Trainer:
                 rows = E * len(self.policy_map[pol])
                 if (FusedPolicyForward.supports(m, obs_size) and self.obs.dtype == torch.float32
                         and rows >= int(tcfg.get("fused_policy_forward_min_rows", 0))):
-                    self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size)
+                    self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size,
+                                                                  arithmetic=str(tcfg.get("policy_arithmetic", "bf16x3")))
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
         # ---- the whole tick in THREE launches (`trainer.fused_tick`, default on): every policy's forward in one launch
         # with the actions drawn in its epilogue, the env's step + reset on those actions, the bookkeeping
