@@ -28,4 +28,3 @@ for update, rollout, fused, fast, arith in CASES:
           f"-> {dt/tr.batch_len*1e3:.3f} ms/tick, {tr.train_batch_size/dt:.3e} env-steps/s; training iteration {it*1e3:.0f} ms "
           f"(rollout {(s0.rollout_time - r0)/4*1e3:.0f} + update {(s0.training_time - u0)/4*1e3:.0f}) -> {tr.train_batch_size/it:.3e} env-steps/s end to end", flush=True)
     tr.graceful_close()
-os._exit(0)  # (a profiler attached to this process must not wait for library teardown)
