@@ -178,7 +178,7 @@ def test_graph_and_eager_rollouts_agree(tmp_path):
             assert trainer._tick_graph is not None
         else:      # ... so the eager run does the same 3 ticks first
             for _ in range(3):
-                trainer._b_idx.zero_()
+                trainer._b_rows.zero_()
                 trainer._tick()
             trainer._generate_rollout_batch()
             assert trainer._tick_graph is None
@@ -213,7 +213,7 @@ def test_fused_policy_forward_in_the_rollout(tmp_path):
         ov["trainer"]["fused_tick"] = False  # (this test compares the probability tensors: the three-launch tick never writes them)
         tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"f{int(fused)}"), verbose=False)
         assert all((f is not None) == fused for f in tr._fused_forward.values())
-        tr._b_idx.zero_()
+        tr._b_rows.zero_()
         tr._tick()  # one tick from identical states and identical initial weights
         torch.cuda.synchronize()
         res[fused] = dict(probs=[p.clone() for p in tr.probs], obs={p: tr.batch[p]["obs"][0].clone() for p in tr.policies},
@@ -360,3 +360,67 @@ def test_three_launch_tick_equals_the_per_op_tick(tmp_path):
         m = tr.train(2)
         assert all(np.isfinite(m[pol]["Total loss"]) for pol in tr.policies)
         tr.graceful_close()
+
+
+@pytest.mark.parametrize("algo,heads,norm", [("A2C", [21, 21], False), ("PPO", [21, 21], True), ("A2C", [5], True)])
+def test_fused_objective_equals_autograd(algo, heads, norm):
+    """HipPolicyGradientHead (objective + gradient with respect to the network's output in one kernel) against the
+    framework path it replaces -- softmax, Categorical log-probability / entropy, MSE, autograd -- on the same
+    output tensor: loss and every logged term to 1e-6 relative, the gradient to 1e-6 of its largest entry.
+    (The framework path itself is pinned to the reference's objectives by tests/test_trainer_cpu.py.)"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training import update_kernels
+    from warp_drive_amd.training.losses import A2C, PPO
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    assert update_kernels.install(fm) is not None
+    torch.manual_seed(len(heads) + norm)
+    T, E, n, W = 7, 61, 9, sum(heads) + 1
+    dev = torch.device("cuda:0")
+    out = (torch.randn(T, E, n, W, device=dev) * 2.0).requires_grad_(True)
+    actions = torch.stack([torch.randint(0, a, (T, E, n), device=dev) for a in heads], dim=-1).to(torch.int32)
+    rewards = torch.randn(T, E, n, device=dev)
+    done = (torch.rand(T, E, device=dev) < 0.1).to(torch.int32)
+    kw = dict(discount_factor_gamma=0.97, normalize_advantage=norm, normalize_return=norm, vf_loss_coeff=0.7,
+              entropy_coeff=0.03)
+    obj = A2C(**kw) if algo == "A2C" else PPO(clip_param=0.2, **kw)
+    loss_f, m_f = obj.compute_loss_and_metrics_from_logits(0, out, actions, rewards, done, heads, True)
+    (g_f,) = torch.autograd.grad(loss_f, out)
+    probs, start = [], 0
+    for a in heads:
+        probs.append(torch.softmax(out[..., start:start + a], dim=-1))
+        start += a
+    loss_r, m_r = obj.compute_loss_and_metrics(timestep=0, actions_batch=actions.long(), rewards_batch=rewards,
+                                               done_flags_batch=done, action_probabilities_batch=probs,
+                                               value_functions_batch=out[..., start], perform_logging=True)
+    (g_r,) = torch.autograd.grad(loss_r, out)
+    assert abs(float(loss_f) - float(loss_r)) <= 1e-6 * max(1.0, abs(float(loss_r))), (float(loss_f), float(loss_r))
+    assert float((g_f - g_r).abs().max()) <= 1e-6 * float(g_r.abs().max()), float((g_f - g_r).abs().max())
+    assert set(m_f) == set(m_r)
+    for k in m_r:
+        assert abs(m_f[k] - m_r[k]) <= 2e-6 * max(1.0, abs(m_r[k])), (k, m_f[k], m_r[k])
+    update_kernels.install(None)
+
+
+@pytest.mark.parametrize("R,C", [(10007, 256), (4096, 64), (333, 128)])
+def test_relu_backward_with_column_sums(R, C):
+    """HipReluBackwardColumnSums: mask + bias gradient in one pass = threshold_backward followed by a column sum"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training.update_kernels import UpdateKernels
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    k = UpdateKernels(fm)
+    torch.manual_seed(R)
+    g = torch.randn(R, C, device="cuda")
+    y = torch.relu(torch.randn(R, C, device="cuda"))
+    assert k.supports_relu_backward(g, y)
+    got, sums = k.relu_backward_colsum(g, y)
+    want = torch.ops.aten.threshold_backward(g, y, 0)
+    assert torch.equal(got, want)
+    assert torch.allclose(sums, want.sum(0), rtol=1e-5, atol=1e-4)

@@ -114,6 +114,8 @@ struct MlpArgs {
   float *values;          // [n_rows] or null
   float *obs_out;         // [T, n_rows, F] training-batch copy of the rows, or null
   const long long *batch_row;  // device counter: which T-row of obs_out (null: row 0)
+  int batch_row_stride;   // 0: one counter for the launch; 1: one per replica (all equal: HipRolloutRecord advances
+                          // each replica's own, so no kernel needs a cross-block hand-over to advance a shared one)
   // ---- actions drawn in the epilogue (two heads; rng_state null: no sampling).  Same counters, same search as the
   // env's fused tick (tag_continuous.hip::tc_sample_heads): Philox counter (row, epoch, stream_tag, 3), words 0 / 1 for
   // the two heads, inverse CDF on the float32 running sum of the probabilities this kernel would have written
@@ -196,7 +198,7 @@ __device__ __forceinline__ void mlp_epilogue(const MlpArgs &p, float *lds, mlp_v
                                    wd_u01_open_closed(head ? rnd.y : rnd.x));
       p.actions[2 * (long)row + head] = a;
       if (p.act_out) {
-        const long long t = p.batch_row ? *p.batch_row : 0;
+        const long long t = p.batch_row ? p.batch_row[(long)(row / p.N) * p.batch_row_stride] : 0;
         p.act_out[2 * ((long)t * p.n_rows + (g - j + ag)) + head] = a;
       }
       if (head == 0) p.rng_state[WD_RNG_HEADER + row] = epoch + 1u;
@@ -243,7 +245,7 @@ __device__ __forceinline__ void mlp_impl(const MlpArgs &p, float *lds) {
     const float *row = p.obs + src_row * p.F;
     float *out = nullptr;
     if (p.obs_out && valid) {
-      const long long t = p.batch_row ? *p.batch_row : 0;
+      const long long t = p.batch_row ? p.batch_row[(long)env * p.batch_row_stride] : 0;
       out = p.obs_out + ((long)t * p.n_rows + g) * p.F;
     }
 #pragma unroll
@@ -436,7 +438,7 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
     const float *row = p.obs + src_row * p.F;
     float *out = nullptr;
     if (p.obs_out && valid) {
-      const long long t = p.batch_row ? *p.batch_row : 0;
+      const long long t = p.batch_row ? p.batch_row[(long)env * p.batch_row_stride] : 0;
       out = p.obs_out + ((long)t * p.n_rows + g) * p.F;
     }
 #pragma unroll
@@ -520,6 +522,7 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   p.obs = obs; p.F = F; p.N = N; p.agent_ids = agent_ids; p.id0 = id0; p.n_pol = n_pol; p.n_rows = n_rows;         \
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.A0 = A0; p.A1 = A1;             \
   p.probs0 = probs0; p.probs1 = probs1; p.values = values; p.obs_out = obs_out; p.batch_row = batch_row; \
+  p.batch_row_stride = 0;                                                                              \
   p.rng_state = nullptr; p.actions = nullptr; p.act_out = nullptr; p.stream_tag = 0; p.tile0 = 0;
 
 // HipPolicyMlpAct_*: ALL policies of a rollout tick in ONE launch (blocks [0, first_block_b) serve policy A, the rest
@@ -538,7 +541,7 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   const bool second = (int)blockIdx.x >= first_block_b; /* block-uniform: scalar selects */           \
   MlpArgs p;                                                                                          \
   p.obs = obs; p.F = F; p.N = N; p.A0 = A0; p.A1 = A1; p.probs0 = probs0; p.probs1 = probs1;          \
-  p.values = nullptr; p.batch_row = batch_row; p.rng_state = rng_state; p.actions = actions;          \
+  p.values = nullptr; p.batch_row = batch_row; p.batch_row_stride = 1; p.rng_state = rng_state; p.actions = actions; \
   p.stream_tag = stream_tag; p.tile0 = second ? first_block_b * (int)(blockDim.x >> 6) : 0;           \
   p.agent_ids = second ? b_agent_ids : a_agent_ids; p.id0 = second ? b_id0 : a_id0;                   \
   p.n_pol = second ? b_n_pol : a_n_pol; p.n_rows = second ? b_n_rows : a_n_rows;                      \
@@ -585,20 +588,22 @@ WD_MLP_KERNEL(64, 64, 3)
 
 // HipRolloutRecord: the trainer's per-tick bookkeeping as ONE launch (it used to be ~20 framework kernels per tick:
 // index_select / index_copy_ per policy and array, the episodic-reward sums -- 100 us of the 670 us tick at
-// configs[2]).  After the env tick: row t (= *batch_row) of every policy's reward batch and of the done batch, the
-// running episodic reward per (replica, agent), and -- for replicas that finished on this tick -- the per-replica
-// sums the "Mean episodic reward" metric is made of (trainer_base.py:408-426, :514-601 keep the same quantities on
-// the host).  One block per replica.  `slot[a]` = policy * 65536 + index of agent a inside its policy.  The last
-// block to finish advances the batch row (every block has read it by then).
+// configs[2]).  After the env tick: row t of every policy's reward batch and of the done batch, the running episodic
+// reward per (replica, agent), and -- for replicas that finished on this tick -- the per-replica sums the "Mean
+// episodic reward" metric is made of (trainer_base.py:408-426, :514-601 keep the same quantities on the host).
+// One block per replica; t = batch_row[replica], which the block advances itself: every replica carries its own copy
+// of the batch row, so nothing is handed over between blocks (a shared counter advanced by "the last block to
+// finish" cost 2000 serialised atomics: 48 us per tick).  `slot[a]` = policy * 65536 + index of agent a inside its
+// policy.
 __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *__restrict__ done, int n_agents,
-                                 int n_envs, const int *__restrict__ slot, long long *batch_row, int *blocks_done,
+                                 int n_envs, const int *__restrict__ slot, long long *batch_row,
                                  int *done_batch, float *ep_count, float *reward_batch_a, float *ep_reward_a,
                                  float *ep_sum_a, int n_pol_a, float *reward_batch_b, float *ep_reward_b,
                                  float *ep_sum_b, int n_pol_b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rec_smem[];
   float *const s_total = (float *)rec_smem;  // [n_agents] episodic reward of the agents of a replica that just finished
   const int e = blockIdx.x, tid = threadIdx.x;
-  const long long t = *batch_row;
+  const long long t = batch_row[e];
   const bool finished = done[e] > 0;
   for (int a = tid; a < n_agents; a += blockDim.x) {
     const int sl = slot[a], pol = sl >> 16, la = sl & 0xffff;
@@ -610,7 +615,10 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
     *acc = finished ? 0.0f : total;
     if (finished) s_total[a] = total;
   }
-  if (tid == 0) done_batch[(long)t * n_envs + e] = done[e];
+  if (tid == 0) {
+    done_batch[(long)t * n_envs + e] = done[e];
+    batch_row[e] = t + 1;
+  }
   if (finished) {  // block-uniform, once per episode and replica
     __syncthreads();
     if (tid < 2 && (tid == 0 || n_pol_b > 0)) {  // thread p: policy p's agents, in agent order (deterministic sum)
@@ -621,13 +629,116 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
     }
     if (tid == 0) ep_count[e] += 1.0f;
   }
+}
+
+// HipPolicyGradientHead: everything between the network's output and its gradient in ONE pass over the batch.  The
+// A2C / PPO objective (reference algorithms/policygradient/a2c.py:97-194, ppo.py:150-228) on `out` [R][W] (W = A0 + A1
+// + 1: the logits of the two heads -- A1 = 0: one head -- then the value) is
+//     loss = mean(-logp(a) * adv) + vf_coeff * mean((v - ret)^2) - ent_coeff * sum_heads mean(H(p_head))
+// (PPO, single epoch: ratio = exp(logp - logp.detach()) = 1, the same gradient; its VALUE is -mean(adv)), with adv / ret
+// precomputed per row (discounted returns, normalisation: small [T, E, n] tensors).  The framework spends ~60
+// element-wise / reduction kernels over [R, 21] tensors on it, forward and backward (R = 1e7 rows at configs[2]: ~30 ms
+// of a 110 ms update); the gradient has a closed form,
+//     d loss / d z_h[j] = (adv * (p_h[j] - [j == a_h]) + ent_coeff * p_h[j] * (log p_h[j] + H_h)) / R,
+//     d loss / d v = 2 vf_coeff (v - ret) / R,
+// so one kernel reads `out`, `actions`, `adv`, `ret` and writes `grad` [R][W] plus four partial sums per block
+// (sum logp * adv, sum of the heads' entropies, sum (v - ret)^2, sum adv) from which the host forms the loss and the
+// logged metrics.  256 rows per block, staged through LDS (coalesced row-major copies in and out; a thread then
+// owns one row: stride W floats, conflict-free for odd W).
+__global__ void __launch_bounds__(256) HipPolicyGradientHead(const float *__restrict__ out, const int *__restrict__ actions,
+                                                             const float *__restrict__ adv, const float *__restrict__ ret,
+                                                             float *__restrict__ grad, float *__restrict__ sums, int R,
+                                                             int A0, int A1, float inv_R, float ent_coeff, float vf_coeff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pg_smem[];
+  float *const tile = (float *)pg_smem;  // [256][W]
+  const int W = A0 + A1 + 1, n_heads = A1 > 0 ? 2 : 1;
+  const int tid = threadIdx.x;
+  const long row0 = (long)blockIdx.x * 256;
+  const int rows = (int)min((long)256, (long)R - row0);
+  const int n = rows * W;
+  for (int q = tid; q < n; q += 256) tile[q] = out[row0 * W + q];
   __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    if (atomicAdd(blocks_done, 1) == (int)gridDim.x - 1) {
-      *blocks_done = 0;
-      *batch_row = t + 1;
+  float s_pg = 0.0f, s_ent = 0.0f, s_vf = 0.0f, s_adv = 0.0f;
+  if (tid < rows) {
+    float *const z = tile + tid * W;
+    const long row = row0 + tid;
+    const float a = adv[row];
+    float logp_taken = 0.0f;
+#pragma unroll 1
+    for (int hd = 0; hd < n_heads; ++hd) {
+      float *const zh = z + (hd ? A0 : 0);
+      const int A = hd ? A1 : A0;
+      const int taken = actions[row * n_heads + hd];
+      float m = -__builtin_inff();
+      for (int j = 0; j < A; ++j) m = fmaxf(m, zh[j]);
+      float total = 0.0f;
+      for (int j = 0; j < A; ++j) total += expf(zh[j] - m);
+      const float lse = m + logf(total);
+      float H = 0.0f;
+      for (int j = 0; j < A; ++j) {
+        const float lp = zh[j] - lse;
+        H -= expf(lp) * lp;
+      }
+      logp_taken += zh[min(max(taken, 0), A - 1)] - lse;
+      for (int j = 0; j < A; ++j) {
+        const float lp = zh[j] - lse, pj = expf(lp);
+        zh[j] = (a * (pj - (j == taken ? 1.0f : 0.0f)) + ent_coeff * pj * (lp + H)) * inv_R;
+      }
+      s_ent += H;
     }
+    const float d = z[W - 1] - ret[row];
+    z[W - 1] = 2.0f * vf_coeff * d * inv_R;
+    s_pg = logp_taken * a;
+    s_vf = d * d;
+    s_adv = a;
+  }
+  __syncthreads();
+  for (int q = tid; q < n; q += 256) grad[row0 * W + q] = tile[q];
+  // block sums (wave shuffles, then the four wavefronts' partials through LDS, in a fixed order: deterministic)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_pg += __shfl_down(s_pg, off);
+    s_ent += __shfl_down(s_ent, off);
+    s_vf += __shfl_down(s_vf, off);
+    s_adv += __shfl_down(s_adv, off);
+  }
+  __syncthreads();  // (the tile is free again)
+  if ((tid & 63) == 0) {
+    float *const w = tile + (tid >> 6) * 4;
+    w[0] = s_pg; w[1] = s_ent; w[2] = s_vf; w[3] = s_adv;
+  }
+  __syncthreads();
+  if (tid < 4) sums[(long)blockIdx.x * 4 + tid] = tile[tid] + tile[4 + tid] + tile[8 + tid] + tile[12 + tid];
+}
+
+// HipReluBackwardColumnSums: g = gx * [y > 0] (the ReLU mask of a hidden layer's backward) AND the column sums of g
+// (that layer's bias gradient) in one pass: the framework's threshold_backward + the two-stage column sum read the
+// [R, C] gradient twice more (10 GB each at configs[2]).  C in {16 .. 256} with C / 4 a divisor of 256; block = 256
+// threads = C / 4 column quads x 1024 / C row phases; `rows_per_block` rows per block; partial[blockIdx.x][C] holds the block's sums (summed
+// over the blocks by the caller).  In place when g == gx.
+__global__ void __launch_bounds__(256) HipReluBackwardColumnSums(const float *__restrict__ gx, const float *__restrict__ y,
+                                                                 float *__restrict__ g, float *__restrict__ partial,
+                                                                 long R, int C, int rows_per_block) {
+  __shared__ float s_part[1024];  // [rows_per_pass][C]: 256 / (C / 4) row phases x C columns = 1024 floats
+  const int tid = threadIdx.x, quads = C >> 2;
+  const int rows_per_pass = 256 / quads;  // (C = 256: 64 lanes per row, 4 rows per pass; C / 4 divides 256)
+  const int cq = tid % quads, rp = tid / quads;
+  const long r_begin = (long)blockIdx.x * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (long r = r_begin + rp; r < r_end; r += rows_per_pass) {
+    const float4 a = *(const float4 *)(gx + r * C + 4 * cq), b = *(const float4 *)(y + r * C + 4 * cq);
+    float4 o;
+    o.x = b.x > 0.0f ? a.x : 0.0f; o.y = b.y > 0.0f ? a.y : 0.0f;
+    o.z = b.z > 0.0f ? a.z : 0.0f; o.w = b.w > 0.0f ? a.w : 0.0f;
+    *(float4 *)(g + r * C + 4 * cq) = o;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  *(float4 *)(s_part + rp * C + 4 * cq) = acc;
+  __syncthreads();
+  if (tid < C) {  // the row phases of a column, in a fixed order
+    float sum = 0.0f;
+    for (int k = 0; k < rows_per_pass; ++k) sum += s_part[k * C + tid];
+    partial[(long)blockIdx.x * C + tid] = sum;
   }
 }
 }

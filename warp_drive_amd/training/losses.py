@@ -116,6 +116,44 @@ class A2C:
                 metrics["Num of Negative Sampled Envs"] = len(neg_env_ids)
         return loss, metrics
 
+    def compute_loss_and_metrics_from_logits(self, timestep, out, actions_batch, rewards_batch, done_flags_batch, head_sizes, perform_logging):
+        """`compute_loss_and_metrics` on the network's raw output `out` [T, E, n, W] (logits of every head, then the value)
+        with the objective and its gradient formed by ONE kernel (training/update_kernels.py::FusedObjective): same loss,
+        same gradient, same metric names.  The returns / advantages -- small [T, E, n] tensors -- are the code above."""
+        from warp_drive_amd.training.update_kernels import FusedObjective
+
+        values_detached = out[..., -1].detach()
+        returns = discounted_returns(rewards_batch, done_flags_batch, values_detached, self.discount_factor_gamma)
+        norm_returns = _normalise(returns) if self.normalize_return else returns
+        advantages = norm_returns - values_detached
+        norm_adv = _normalise(advantages) if self.normalize_advantage else advantages
+        vf_c = self.vf_loss_coeff_schedule.get_param_value(timestep)
+        ent_c = self.entropy_coeff_schedule.get_param_value(timestep)
+        W = out.shape[-1]
+        loss, terms = FusedObjective.apply(out.reshape(-1, W), actions_batch.reshape(-1, actions_batch.shape[-1]).to(torch.int32).contiguous(),
+                                           norm_adv.reshape(-1).contiguous(), norm_returns.reshape(-1).contiguous(),
+                                           tuple(int(a) for a in head_sizes), float(ent_c), float(vf_c), self.clip_param is not None)
+        metrics = {}
+        if perform_logging:
+            policy_loss, vf_loss, mean_entropy = (float(v) for v in terms.tolist())
+            var_explained = torch.clamp(1 - norm_adv.var() / (norm_returns.var() + _EPSILON), min=-1.0)
+            metrics = {
+                "VF loss coefficient": vf_c, "Entropy coefficient": ent_c, "Total loss": loss.item(),
+                "Policy loss": policy_loss, "Value function loss": vf_loss,
+                "Mean rewards": rewards_batch.mean().item(), "Max. rewards": rewards_batch.max().item(),
+                "Min. rewards": rewards_batch.min().item(), "Mean value function": values_detached.mean().item(),
+                "Mean advantages": advantages.mean().item(), "Mean (norm.) advantages": norm_adv.mean().item(),
+                "Mean (discounted) returns": returns.mean().item(), "Mean normalized returns": norm_returns.mean().item(),
+                "Mean entropy": mean_entropy, "Variance explained by the value function": var_explained.item(),
+            }
+            af = actions_batch.float()
+            over_agents, over_time, over_envs = (af.std(dim=d).mean(dim=(0, 1)) for d in (2, 0, 1))
+            for h in range(af.shape[-1]):
+                metrics[f"Std. of action_{h} over agents"] = over_agents[h].item()
+                metrics[f"Std. of action_{h} over envs"] = over_envs[h].item()
+                metrics[f"Std. of action_{h} over time"] = over_time[h].item()
+        return loss, metrics
+
 
 class PPO(A2C):
     def __init__(self, clip_param=0.1, **kwargs):

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from warp_drive_amd.training import update_kernels
 from warp_drive_amd.utils.spaces import Box, Dict, Discrete, MultiDiscrete
 
 
@@ -76,6 +77,17 @@ class FullyConnected(nn.Module):
             probs.append(torch.softmax(out[..., start:start + a], dim=-1))
             start += a
         return probs, out[..., start]
+
+    def forward_logits(self, obs):
+        """obs [..., obs_size] -> [..., sum(head_sizes) + 1]: the logits of every head, then the value -- what `forward`
+        turns into probabilities; the fused objective (training/update_kernels.py) works on this tensor directly"""
+        x = obs
+        for i in range(len(self.fc)):
+            lin = self.fc[str(i)][0]
+            x = _Affine.apply(x, lin.weight, lin.bias, True)
+        w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
+        b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
+        return _Affine.apply(x, w, b, False)
 
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
@@ -153,12 +165,18 @@ class _Affine(torch.autograd.Function):
     def backward(ctx, g):
         x2, wc, y = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).to(x2.dtype)
+        gb = None
         if ctx.relu:
-            g2 = torch.ops.aten.threshold_backward(g2, y, 0)
+            kernels = update_kernels.active()
+            if kernels is not None and kernels.supports_relu_backward(g2, y):
+                g2, gb = kernels.relu_backward_colsum(g2, y)  # mask + bias gradient in one pass over the gradient
+            else:
+                g2 = torch.ops.aten.threshold_backward(g2, y, 0)
         with torch.autocast(device_type=g.device.type, enabled=False):
             gx = (g2 @ wc).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
             gw = _weight_grad(g2, x2)
-            gb = _column_sums(g2)
+            if gb is None:
+                gb = _column_sums(g2)
         return gx, gw, gb, None
 
 

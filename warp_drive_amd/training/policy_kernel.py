@@ -176,7 +176,8 @@ class FusedRolloutTick:
       (the env's `TickA` entry: step + reset of finished replicas on those actions -- RolloutEngine(presampled_actions=True))
       record()   HipRolloutRecord: rewards / done into row t of the batches, the episodic-reward bookkeeping, t += 1.
 
-    `batch_row` is the device counter t (int64 [1]); everything is enqueued on torch's current stream and is free of
+    `batch_row` is the device counter t, one copy per replica (int64 [E], all equal: each replica's record block advances
+    its own, so no kernel hands anything over between blocks); everything is enqueued on torch's current stream and is free of
     host-side indices, so a tick can be captured in a hipGraph."""
 
     def __init__(self, function_manager, forwards, agent_ids, obs, actions, rewards, done, rng_state, stream_tag,
@@ -216,13 +217,13 @@ class FusedRolloutTick:
         if len(forwards) == 1:
             per_policy.append([null, np.int32(0), np.int32(1), np.int32(0)] + [null] * 8)
         self.slot = torch.from_numpy(slot.astype(np.int32)).to(dev)
-        self.blocks_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert batch_row.dtype == torch.int64 and batch_row.numel() == E
         self.fwd_args = [obs, np.int32(F), np.int32(N), np.int32(f0.heads[0]), np.int32(f0.heads[1]), null, null, batch_row,
                          rng_state, actions, np.int32(stream_tag), np.int32(blocks[0] if len(forwards) == 2 else 2 ** 30),
                          *per_policy[0], *per_policy[1]]
         self.fwd_grid, self.fwd_block = (sum(blocks), 1), (64 * f0.WAVES_PER_BLOCK, 1, 1)
         second = len(forwards) == 2
-        self.rec_args = [rewards, done, np.int32(N), np.int32(E), self.slot, batch_row, self.blocks_done, done_batch, ep_count,
+        self.rec_args = [rewards, done, np.int32(N), np.int32(E), self.slot, batch_row, done_batch, ep_count,
                          reward_batches[0], ep_rewards[0], ep_sums[0], np.int32(per_policy[0][2]),
                          reward_batches[1] if second else null, ep_rewards[1] if second else null,
                          ep_sums[1] if second else null, np.int32(per_policy[1][2]) if second else np.int32(0)]

@@ -30,6 +30,7 @@ from warp_drive_amd.rollout import RolloutEngine
 from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
+from warp_drive_amd.training import update_kernels
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
 from warp_drive_amd.training.policy_kernel import (FusedPolicyForward, FusedRolloutTick, pack_gridworld_policy, pack_rollout_policy,
                                                     rollout_policy_width)
@@ -186,7 +187,10 @@ class Trainer:
         self.perf_stats = PerfStats()
         self.metrics = {}
         # rollout tick as a hipGraph: needs a single-launch env tick (no Python-side branching)
-        self._b_idx = torch.zeros(1, dtype=torch.long, device=self.device)  # batch row of the current tick
+        # batch row of the current tick, one copy per replica (element 0 is "the" counter of the framework-op path; the
+        # three-launch tick's record kernel advances every replica's own)
+        self._b_rows = torch.zeros(E, dtype=torch.long, device=self.device)
+        self._b_idx = self._b_rows[:1]
         self._tick_graph = None
         self._want_graph = bool(tcfg.get("graph_rollout", False)) and self.engine.fused
         # precision of the policy forward in the ROLLOUT (the update always runs in float32, as the
@@ -208,6 +212,12 @@ class Trainer:
                     self._fused_forward[pol] = FusedPolicyForward(env_wrapper.cuda_function_manager, m, obs_size,
                                                                   arithmetic=str(tcfg.get("policy_arithmetic", "bf16x3")))
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
+        # ---- the update's non-GEMM work as hand-written kernels (`trainer.fused_update`, default on; one or two heads)
+        self._fused_update = False
+        if bool(tcfg.get("fused_update", True)) and self.device.type == "cuda" and len(self.head_sizes) <= 2 \
+                and sum(self.head_sizes) + 1 <= 64:
+            update_kernels.install(env_wrapper.cuda_function_manager)
+            self._fused_update = True
         # ---- the whole tick in THREE launches (`trainer.fused_tick`, default on): every policy's forward in one launch
         # with the actions drawn in its epilogue, the env's step + reset on those actions, the bookkeeping
         # (training/policy_kernel.py::FusedRolloutTick).  Needs: every policy on the fused forward with one network
@@ -223,7 +233,7 @@ class Trainer:
             self._fast_tick = FusedRolloutTick(
                 env_wrapper.cuda_function_manager, fw, [self.ids[pol] for pol in self.policies],
                 self.obs.reshape(E, N, -1), self.actions, self.rewards, self.done, self.sampler.rng_state,
-                _stream_tag("tick"), self._b_idx, [self.batch[pol]["obs"] for pol in self.policies],
+                _stream_tag("tick"), self._b_rows, [self.batch[pol]["obs"] for pol in self.policies],
                 [self.batch[pol]["actions"] for pol in self.policies], [self.batch[pol]["rewards"] for pol in self.policies],
                 self.done_batch, [self._ep_reward[pol] for pol in self.policies],
                 [self._ep_sum[pol] for pol in self.policies], self._ep_cnt)
@@ -348,12 +358,12 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):   # allocator / library warm-up outside the capture
                 for _ in range(3):
-                    self._b_idx.zero_()
+                    self._b_rows.zero_()
                     self._tick()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            self._b_idx.zero_()
+            self._b_rows.zero_()
             with torch.cuda.graph(graph):
                 self._tick()
             torch.cuda.synchronize()
@@ -398,7 +408,7 @@ class Trainer:
         if self._tick_graph is None and self._want_graph:
             self._tick_graph = self._capture_tick_graph()
             self._want_graph = self._tick_graph is not None
-        self._b_idx.zero_()
+        self._b_rows.zero_()
         for _ in range(self.batch_len):
             if self._tick_graph is not None:
                 self._tick_graph.replay()
@@ -415,6 +425,19 @@ class Trainer:
         self.grad_bucket.zero()  # (the .grad views stay attached to the bucket: no zero_grad(set_to_none))
         for pol in trained:
             batch = self.batch[pol]
+            if self._fused_update and self.neg_pos_env_ratio <= 0:
+                # the objective and its gradient with respect to the network's output as ONE kernel, the ReLU masks and
+                # bias gradients of the backward as one pass each (training/update_kernels.py); the GEMMs are the framework's
+                with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
+                                    enabled=self._update_dtype is not None):
+                    out = self.models[pol].forward_logits(batch["obs"][: self.batch_len])
+                loss, m = self.trainers[pol].compute_loss_and_metrics_from_logits(
+                    self.current_timestep[pol], out.float(), batch["actions"][: self.batch_len],
+                    batch["rewards"][: self.batch_len], done[: self.batch_len], self.head_sizes, log)
+                loss.backward()
+                if log:
+                    metrics[pol] = m
+                continue
             with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
                                 enabled=self._update_dtype is not None):
                 probs, values = self.models[pol](batch["obs"][: self.batch_len])

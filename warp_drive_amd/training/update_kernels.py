@@ -1,0 +1,97 @@
+"""The update's non-GEMM work as hand-written kernels (csrc/kernels/policy_mlp.hip, the trainer's code object).
+
+At configs[2] a training batch is ~1e7 rows.  The GEMMs of the update are the framework's (hipBLASLt, ~65 % of the
+float32 matrix peak); everything AROUND them used to be framework element-wise / reduction kernels over [rows, 21] and
+[rows, 256] tensors -- as much time as the GEMMs (profiles/r05_update_kernels.txt).  Two kernels replace most of it:
+
+  policy_gradient_head   HipPolicyGradientHead: A2C / PPO objective + its gradient with respect to the network's output
+                         in ONE pass (softmax of both heads, log-probability of the taken actions, entropies, value
+                         loss; reference algorithms/policygradient/a2c.py:97-194, ppo.py:150-228)
+  relu_backward_colsum   HipReluBackwardColumnSums: the ReLU mask of a hidden layer's backward and that layer's bias
+                         gradient in one pass over the [rows, features] gradient
+
+`install(function_manager)` makes them available to training/models.py and training/losses.py; without it (CPU tests,
+other devices) both modules run their framework paths."""
+import numpy as np
+import torch
+
+_ACTIVE = {"kernels": None}
+
+
+def active():
+    return _ACTIVE["kernels"]
+
+
+def install(function_manager):
+    _ACTIVE["kernels"] = UpdateKernels(function_manager) if function_manager is not None else None
+    return _ACTIVE["kernels"]
+
+
+class UpdateKernels:
+    ROWS_PER_BLOCK = 4096   # HipReluBackwardColumnSums: rows per block (a [blocks, C] partial-sum tensor is reduced after it)
+
+    def __init__(self, function_manager):
+        names = ["HipPolicyGradientHead", "HipReluBackwardColumnSums"]
+        function_manager.initialize_functions(names)
+        self.head_fn, self.relu_fn = (function_manager.get_function(n) for n in names)
+
+    # ------------------------------------------------------------------------------------------------ objective
+    @staticmethod
+    def supports_head(out, head_sizes):
+        W = sum(head_sizes) + 1
+        return (out.is_cuda and out.dtype == torch.float32 and 1 <= len(head_sizes) <= 2 and W <= 64
+                and out.shape[-1] == W)
+
+    def policy_gradient_head(self, out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff):
+        """out [R, W] float32, actions [R, n_heads] int32, adv / ret [R] float32 ->
+        (grad [R, W] = d loss / d out, sums float64 [4] = sum logp * adv, sum of entropies, sum (v - ret)^2, sum adv)"""
+        R, W = out.shape
+        assert out.is_contiguous() and actions.is_contiguous() and adv.is_contiguous() and ret.is_contiguous()
+        assert actions.dtype == torch.int32 and tuple(actions.shape) == (R, len(head_sizes)) and adv.numel() == R == ret.numel()
+        grad = torch.empty_like(out)
+        blocks = (R + 255) // 256
+        sums = torch.empty((blocks, 4), dtype=torch.float32, device=out.device)
+        a1 = int(head_sizes[1]) if len(head_sizes) > 1 else 0
+        self.head_fn(out, actions, adv, ret, grad, sums, np.int32(R), np.int32(head_sizes[0]), np.int32(a1),
+                     np.float32(1.0 / R), np.float32(ent_coeff), np.float32(vf_coeff),
+                     block=(256, 1, 1), grid=(blocks, 1), shared=4 * 256 * W)
+        return grad, sums.sum(dim=0, dtype=torch.float64)
+
+    # --------------------------------------------------------------------------------------------- hidden layers
+    @staticmethod
+    def supports_relu_backward(g, y):
+        C = g.shape[-1]
+        return (g.is_cuda and g.dtype == torch.float32 and y.dtype == torch.float32 and g.is_contiguous()
+                and y.is_contiguous() and g.shape == y.shape and C % 4 == 0 and 16 <= C <= 256 and 256 % (C // 4) == 0)
+
+    def relu_backward_colsum(self, g, y):
+        """g, y [R, C] float32 -> (g * [y > 0] as a new tensor, its column sums float32 [C])"""
+        R, C = g.shape
+        out = torch.empty_like(g)
+        blocks = (R + self.ROWS_PER_BLOCK - 1) // self.ROWS_PER_BLOCK
+        partial = torch.empty((blocks, C), dtype=torch.float32, device=g.device)
+        self.relu_fn(g, y, out, partial, np.int64(R), np.int32(C), np.int32(self.ROWS_PER_BLOCK),
+                     block=(256, 1, 1), grid=(blocks, 1), shared=0)
+        return out, partial.sum(dim=0)
+
+
+class FusedObjective(torch.autograd.Function):
+    """loss = policy_loss + vf_coeff * vf_loss - ent_coeff * mean_entropy as ONE kernel that also produces d loss / d
+    out; `terms` (float64 [3], detached: policy loss, value loss, mean entropy) is returned beside it for the metrics."""
+
+    @staticmethod
+    def forward(ctx, out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff, ppo):
+        k = active()
+        R = out.shape[0]
+        grad, sums = k.policy_gradient_head(out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff)
+        policy_loss = -(sums[3] if ppo else sums[0]) / R  # PPO at ratio 1: min(ratio * A, clamp(ratio) * A) = A
+        vf_loss, entropy = sums[2] / R, sums[1] / R
+        loss = policy_loss + vf_coeff * vf_loss - ent_coeff * entropy
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(terms := torch.stack([policy_loss, vf_loss, entropy]))
+        return loss.to(torch.float32), terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss.to(grad.dtype), None, None, None, None, None, None, None
