@@ -222,6 +222,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the HIP path"
     device = wdd.device_index(local_rank)
     torch.cuda.set_device(device)
+    pinned = wdd.pin_rank_to_cpus(local_rank, device=device)  # N > 1: every rank on its own CPUs, next to its GPU
     wdd.init_process_group(backend="nccl", device_id=device)  # RCCL; no-op for one rank
 
     from warp_drive_amd.env_wrapper import EnvWrapper
@@ -461,6 +462,7 @@ def main():
             "ms_per_step_spread": {"min": min(repeats) / steps * 1e3, "median": sorted(repeats)[len(repeats) // 2] / steps * 1e3,
                                    "max": max(repeats) / steps * 1e3, "repeats": len(repeats)},
             "per_rank_ms_per_step": per_rank_ms,
+            "cpus_of_rank0": (len(pinned) if pinned else None),  # N > 1: CPUs this rank was pinned to (next to its GPU)
             "allreduce_us": allreduce_us,
             "roofline": {
                 "bound": "hbm", "kernel": engine.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -485,6 +487,20 @@ def main():
             "roofline_valu": valu_roofline(engine.step_kernel_name, E, bool(args.full_obs), kern_us)
             if is_tc else None,
         }
+        if is_tc and args.mode == "plan" and kern_us > 0:
+            # The cost of a TagContinuous tick falls along the episode (agents leave the game), so a `value` timed over a
+            # window that is not a whole number of episodes is the rate of THAT window, not of the workload.  The rate
+            # that belongs next to `roofline.frac` (both from the two whole-episode timing passes) is always printed;
+            # `value` itself is replaced by it when the timed window covers no whole episode.
+            episode_rate = world * E / (kern_us * 1e-6)
+            whole = (steps % T == 0) and steps >= T
+            out["value_episode_average"] = episode_rate
+            out["value_window"] = {"whole_episodes": whole, "env_steps_per_s_of_the_window": out["value"]}
+            if not whole and steps < T:
+                out["value"] = episode_rate
+                out["value_window"]["note"] = (f"the timed window ({steps} ticks from tick {window_first_tick}) is not a whole "
+                                               f"episode ({T} ticks): `value` is the episode-average rate of the HIP-event "
+                                               f"passes; the window's own rate is kept here")
         if not args.no_cpu_baseline and args.workload == "tag_continuous" and world == 1:  # N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline({k: v for k, v in cfg.items()})

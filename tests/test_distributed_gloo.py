@@ -48,16 +48,7 @@ def _worker(rank, world, port, total_envs, out_dir):
     wdd.shutdown()
 
 
-def test_two_rank_sharding(tmp_path):
-    total, world = 7, 2  # ragged on purpose
-    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
-    recs = [json.load(open(tmp_path / f"r_{r}.json")) for r in range(world)]
-    assert [(r["first"], r["count"]) for r in recs] == [(0, 4), (4, 3)]
-    assert [r["seed"] for r in recs] == [274880, 274881]
-    for r in recs:
-        assert r["max_t"] == 2.0 and abs(r["agg"] - 7 * 12 / 2.0) < 1e-9
-        # what bench.py adds to its N > 1 line: every rank's own time, and the gradient bucket's all-reduce time
-        assert r["per_rank"] == [1.0, 2.0] and r["allreduce_us"] > 0
+def _check_against_unsharded(tmp_path, total, world):
     # sharded result == unsharded result: replicas are independent, no collective needed
     from warp_drive_amd.envs.tag_gridworld import TagGridWorld
 
@@ -74,6 +65,54 @@ def test_two_rank_sharding(tmp_path):
         ref.append(np.stack([e.global_state["loc_x"][e.timestep] for e in envs]))
     got = np.concatenate([np.load(tmp_path / f"x_{r}.npy") for r in range(world)], axis=1)
     np.testing.assert_array_equal(got, np.stack(ref))
+
+
+def test_two_rank_sharding(tmp_path):
+    total, world = 7, 2  # ragged on purpose
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    recs = [json.load(open(tmp_path / f"r_{r}.json")) for r in range(world)]
+    assert [(r["first"], r["count"]) for r in recs] == [(0, 4), (4, 3)]
+    assert [r["seed"] for r in recs] == [274880, 274881]
+    for r in recs:
+        assert r["max_t"] == 2.0 and abs(r["agg"] - 7 * 12 / 2.0) < 1e-9
+        # what bench.py adds to its N > 1 line: every rank's own time, and the gradient bucket's all-reduce time
+        assert r["per_rank"] == [1.0, 2.0] and r["allreduce_us"] > 0
+    _check_against_unsharded(tmp_path, total, world)
+
+
+def test_eight_rank_sharding(tmp_path):
+    """the driver's 8-GPU scaling run is the first time this path sees 8 ranks on hardware: the same worker with
+    WORLD_SIZE = 8 over gloo -- contiguous ragged shards that cover every replica once, seeds base + rank, the job's
+    time = the slowest rank's, every rank's own time gathered in rank order, a collective of the gradient bucket's size"""
+    total, world = 21, 8
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    recs = [json.load(open(tmp_path / f"r_{r}.json")) for r in range(world)]
+    assert [r["count"] for r in recs] == [3, 3, 3, 3, 3, 2, 2, 2]
+    assert [r["first"] for r in recs] == [0, 3, 6, 9, 12, 15, 17, 19]
+    assert [r["seed"] for r in recs] == [274880 + r for r in range(world)]
+    xs = np.concatenate([np.load(tmp_path / f"x_{r}.npy") for r in range(world)], axis=1)
+    assert xs.shape[1] == total
+    for r in recs:
+        assert r["max_t"] == 8.0 and abs(r["agg"] - total * 12 / 8.0) < 1e-9
+        assert r["per_rank"] == [float(k + 1) for k in range(world)] and r["allreduce_us"] > 0
+    _check_against_unsharded(tmp_path, total, world)
+
+
+def test_rank_cpu_slices():
+    """`pin_rank_to_cpus`: every rank of a node gets its own, non-empty, disjoint share of the allowed CPUs; with the
+    GPUs' NUMA nodes known, a share of the CPUs next to its GPU"""
+    from warp_drive_amd.distributed import _parse_cpulist, rank_cpu_slice
+
+    allowed = set(range(4, 132))  # 128 CPUs allowed, ids not starting at 0
+    shares = [rank_cpu_slice(r, 8, allowed) for r in range(8)]
+    assert all(len(s) == 16 for s in shares) and sorted(sum(shares, [])) == sorted(allowed)
+    assert rank_cpu_slice(2, 8, {7}) == [7]                       # fewer CPUs than ranks: never empty
+    assert sorted(sum([rank_cpu_slice(r, 3, set(range(10))) for r in range(3)], [])) == list(range(10))  # ragged
+    node1 = _parse_cpulist("64-127,192-255\n")
+    assert len(node1) == 128 and 200 in node1
+    # ranks 4..7 drive GPUs of NUMA node 1: rank 5 is the second of four on it
+    share = rank_cpu_slice(5, 8, set(range(256)), numa_cpus=node1, ranks_on_node=(1, 4))
+    assert len(share) == 32 and set(share) <= node1 and share[0] == 96
 
 
 def test_shard_replicas_covers_everything():
@@ -100,8 +139,8 @@ def test_concurrent_ranks_build_once(tmp_path):
     (what HIPFunctionManager.compile_and_load_hip does without an event messenger)"""
     from warp_drive_amd import build as wd_build
 
-    mp.spawn(_lock_worker, args=(str(tmp_path),), nprocs=3, join=True)
-    for r in range(3):
+    mp.spawn(_lock_worker, args=(str(tmp_path),), nprocs=8, join=True)  # (8: the ranks of one MI355X node)
+    for r in range(8):
         assert open(tmp_path / f"ok_{r}").read() == wd_build.HSACO
     assert os.path.exists(wd_build.HSACO)
 

@@ -25,6 +25,72 @@ def device_index(local_rank=None):
     return int(rank_info()[1] if local_rank is None else local_rank)
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _gpu_numa_cpus(device):
+    """CPUs of the NUMA node the GPU `device` hangs off (sysfs, through the PCI address torch reports), or None"""
+    try:
+        props = torch.cuda.get_device_properties(device)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except Exception:
+        return None
+
+
+def rank_cpu_slice(local_rank, local_world, allowed, numa_cpus=None, ranks_on_node=None):
+    """The CPUs rank `local_rank` of `local_world` ranks on this host should run on: a contiguous share of `allowed`
+    (the process' affinity mask) -- of the part of it on the GPU's own NUMA node when that is known (`numa_cpus`;
+    `ranks_on_node` = (index of this rank among the ranks of that node, their number)).  Never empty."""
+    allowed = sorted(allowed)
+    pool, idx, n = allowed, int(local_rank), max(1, int(local_world))
+    if numa_cpus:
+        near = [c for c in allowed if c in numa_cpus]
+        if near and ranks_on_node is not None:
+            pool, (idx, n) = near, ranks_on_node
+    per = max(1, len(pool) // n)
+    share = pool[idx * per:(idx + 1) * per] if idx < n - 1 else pool[idx * per:]
+    return share or pool or allowed
+
+
+def pin_rank_to_cpus(local_rank=None, local_world=None, device=None):
+    """Give every rank of a node its own CPUs, next to its GPU (sched_setaffinity): with 8 ranks started by one
+    launcher the host threads otherwise float over both sockets, and a rank whose Python thread sits on the far
+    socket issues its launches later than the others -- host-side skew that reads as poor scaling in a weak-scaling
+    run whose time is the SLOWEST rank's.  WD_PIN_CPUS=0 leaves the affinity alone.  Returns the CPU list (or None)."""
+    if os.environ.get("WD_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    _, lr, world = rank_info()
+    local_rank = lr if local_rank is None else int(local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world)) if local_world is None else int(local_world)
+    if local_world <= 1:
+        return None
+    allowed = os.sched_getaffinity(0)
+    numa, on_node = None, None
+    if device is not None and torch.cuda.is_available() and os.environ.get("WD_FORCE_DEVICE") in (None, ""):
+        numa = _gpu_numa_cpus(device)
+        if numa:  # ranks drive device = local rank: the ranks whose GPU sits on the same node share its CPUs
+            same = [r for r in range(local_world)
+                    if r < torch.cuda.device_count() and (_gpu_numa_cpus(r) or set()) == numa]
+            if local_rank in same:
+                on_node = (same.index(local_rank), len(same))
+    share = rank_cpu_slice(local_rank, local_world, allowed, numa, on_node)
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    return sorted(share)
+
+
 def init_process_group(backend=None, device_id=None):
     rank, local_rank, world = rank_info()
     if world == 1:

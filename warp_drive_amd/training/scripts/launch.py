@@ -47,6 +47,7 @@ def child_environment(base=None):
     env = dict(os.environ if base is None else base)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver stack
     env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (as bench.py: read at HIP init)
     return env
 
 

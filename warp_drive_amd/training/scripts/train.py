@@ -10,7 +10,11 @@ import argparse
 import logging
 import os
 
-import torch
+# kernel arguments in device memory instead of host-coherent memory (bench.py: one TagContinuous tick 54.3 -> 50.5 us);
+# read when HIP initialises, so it is set before torch is imported
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 import yaml
 
 from warp_drive_amd import distributed as wdd
@@ -40,6 +44,7 @@ def setup_trainer(env_name, overrides=None, results_dir=None, verbose=True):
     rank, local_rank, world = wdd.rank_info()
     device = wdd.device_index(local_rank)  # one rank per GPU: device = local rank
     torch.cuda.set_device(device)
+    wdd.pin_rank_to_cpus(local_rank, device=device)  # several ranks per node: each on its own CPUs, next to its GPU
     wdd.init_process_group(backend="nccl", device_id=device)
     env_cfg = dict(config["env"])
     # (identical seeded start state on every rank; the action streams differ by seed + rank)
