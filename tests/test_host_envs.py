@@ -82,7 +82,12 @@ def test_tag_continuous_picks_the_entry_point_by_agent_count_and_k():
     assert name(100, 10, full=True) == "HipTagContinuousStep"
 
     # with a function manager that has it, the entry whose sizes are folded at compile time wins (BASELINE shape only)
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+
     class Manager:
+        _num_agents, _num_envs = 105, 4
+        packed_geometry = HIPFunctionManager.packed_geometry  # (the entry is compiled for this geometry's 128 threads)
+
         def has_function(self, fname):
             return fname == "HipTagContinuousStep_K10_N105A21"
 

@@ -46,8 +46,9 @@ UNITS = {
        for k, w, big in ((2, 4, False), (4, 4, True), (6, 4, False), (8, 4, True), (10, 4, True), (12, 3, True),
                          (16, 3, True), (24, 2, False), (32, 2, False))},
     # the BASELINE shape (5 taggers + 100 runners, K = 10, 21-way heads) with its sizes as compile-time constants
+    # (and its block size: 105 agents = one replica per 128-thread block, envs/tag_continuous.py::_geometry)
     "wd_kernels_tc_k10_n105a21.hsaco": ("tag_continuous.hip", ["-DWD_TC_KM=10", "-DWD_TC_SHAPE_N=105",
-                                                                 "-DWD_TC_SHAPE_A=21"]),
+                                                                 "-DWD_TC_SHAPE_A=21", "-DWD_TC_SHAPE_THREADS=128"]),
     "wd_kernels_mlp.hsaco": ("policy_mlp.hip", []),
     "wd_kernels_gw5.hsaco": ("tag_gridworld_n5.hip", []),
     "wd_kernels_test.hsaco": ("wd_test_kernels.hip", []),

@@ -62,6 +62,14 @@
 //     full-observation mode).
 #include "wd_common.h"
 
+// threads per block: a launch-time value, except in the unit that is built for ONE shape (its host geometry is fixed:
+// envs/tag_continuous.py::_geometry), where the number of wavefronts, the replicas per block and every loop over them fold
+#if defined(WD_TC_SHAPE_THREADS)
+#define WD_TC_BLOCKDIM WD_TC_SHAPE_THREADS
+#else
+#define WD_TC_BLOCKDIM ((int)blockDim.x)
+#endif
+
 // Phase probes (experiments/phase_profile.py): compiled out of the product build.  With -DWD_TC_PROBES (variant
 // "prof" of experiments/variant_sets.py) lane 0 of every wavefront of the fast path stamps the shader clock at
 // the phase boundaries into 24 slots per wavefront behind a __device__ pointer the harness sets.
@@ -282,7 +290,7 @@ __device__ __forceinline__ void tc_issue_loads(TcIn &in, const TcArgs &a, const 
 // Returns the number of taggers.  Ends WITHOUT a barrier: the caller's next barrier publishes them.
 __device__ __forceinline__ int tc_build_tables(const TcTables &tb, const TcArgs &a, int N, int n_acc, int n_turn,
                                                bool tab_in_lds, const TcIn &in) {
-  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int tid = threadIdx.x, T_ = WD_TC_BLOCKDIM;
   const int my_type = in.type;
   if (tab_in_lds) {  // (entries loaded up front, before the probability slabs)
     if (tid < n_acc) tb.acc_tab[tid] = in.tab_acc;
@@ -486,7 +494,7 @@ __device__ __forceinline__ void tc_finish_agent(const TcArgs &a, const TcTables 
 // tick to these rows (the caller drains its own stores first).
 __device__ __forceinline__ void tc_reset_finished(const TcArgs &a, const TcFuse &fz, const TcTables &tb, int env0,
                                                   int epb) {
-  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int tid = threadIdx.x, T_ = WD_TC_BLOCKDIM;
   const int envs_here = min(epb, a.E - env0);
   for (int e = 0; e < envs_here; ++e) {
     if (tb.doneflag[e] == 0) continue;  // block-uniform
@@ -1567,7 +1575,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
                                              int n_turn) {
   const int N = a.N, K = EXACTK ? KMAX : a.K;
   const int F = 7 * K + 1;
-  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int tid = threadIdx.x, T_ = WD_TC_BLOCKDIM;
   const int epb = max(1, T_ / N);
   // (readfirstlane: the wavefront index is uniform, but only the hardware knows -- without it every loop whose
   // bounds depend on it is compiled as a divergent loop)
@@ -2081,7 +2089,7 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
   const int N = a.N, K = a.use_full_obs ? 0 : a.K;
   const int W = a.use_full_obs ? (N - 1) : K;  // columns per feature
   const int F = 7 * W + 1;
-  const int tid = threadIdx.x, T_ = blockDim.x;
+  const int tid = threadIdx.x, T_ = WD_TC_BLOCKDIM;
   const int epb = max(1, T_ / N);
   const size_t slab_acc_bytes = tc_align16((size_t)4 * epb * N * n_acc);
   const size_t slab_turn_bytes = tc_align16((size_t)4 * epb * N * n_turn);
@@ -2309,12 +2317,14 @@ __device__ __forceinline__ void tc_generic_impl(const TcArgs &a, const TcFuse &f
 //   -DWD_TC_KM=<k> -DWD_TC_WAVES=<w>   the fast entries for K <= k: `_K<k>` up to 128 agents (7 id bits in the search
 //        [-DWD_TC_BIG]                 keys), `_K<k>_N512` for 129 .. 512 (blocks of up to eight wavefronts, 9 id
 //                                      bits) and, with WD_TC_BIG, `_K<k>_N1024` beyond      -> wd_kernels_tc_k<k>.hsaco
-//   -DWD_TC_KM=<k> -DWD_TC_SHAPE_N=<n> -DWD_TC_SHAPE_A=<a>
-//                                      `_K<k>_N<n>A<a>`: ONE shape (n agents, exactly k observed, a-way action heads)
+//   -DWD_TC_KM=<k> -DWD_TC_SHAPE_N=<n> -DWD_TC_SHAPE_A=<a> -DWD_TC_SHAPE_THREADS=<t>
+//                                      `_K<k>_N<n>A<a>`: ONE shape (n agents, exactly k observed, a-way action heads,
+//                                      blocks of t threads: the launch MUST use them, the host asserts it)
 //                                      with its sizes as compile-time constants -- what the reference gets for EVERY
 //                                      run by templating wkNumberAgents into the source it hands to nvcc
 //                                      (template_env_config.h:19-21); built ahead of time for the BASELINE shape
-//                                      (105 agents, K = 10, 21-way heads: -3.8 % per tick, experiments/README.md)
+//                                      (105 agents, K = 10, 21-way heads, 128 threads: -3.8 % per tick for the sizes, -3.3 % more for
+//                                      the block size, experiments/README.md)
 //                                                                                           -> wd_kernels_tc_k10_n105a21.hsaco
 // Separate objects, so that work on the big-replica search never moves the registers or the code layout of the
 // headline kernel.  Every fast size class has three entries: Step (actions given), Tick (sample both heads + step +

@@ -329,7 +329,7 @@ class TagContinuous(CUDAEnvironmentContext):
         shaped = f"{default_name}_K{K}_N{self.num_agents}A{len(self.acceleration_actions)}"
         fm = getattr(self, "cuda_function_manager", None)
         if (self.SHAPE_ENTRIES and len(self.acceleration_actions) == len(self.turn_actions) and fm is not None
-                and fm.has_function(shaped)):
+                and fm.has_function(shaped) and self._geometry()[1][0] == self.SHAPE_ENTRY_THREADS.get(shaped, -1)):
             return shaped
         for k in (self._K_SPECIALISATIONS_N1024 if big else _K_SPECIALISATIONS):
             if k >= K:
@@ -337,6 +337,8 @@ class TagContinuous(CUDAEnvironmentContext):
         return default_name
 
     SHAPE_ENTRIES = os.environ.get("WD_TC_SHAPE_ENTRIES", "1") != "0"
+    # threads per block the shape-specialised entries are compiled for (-DWD_TC_SHAPE_THREADS, warp_drive_amd/build.py)
+    SHAPE_ENTRY_THREADS = {"HipTagContinuousStep_K10_N105A21": 128}
 
     def lds_bytes(self, epb, fused=False, threads=None):
         """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve_fast /
