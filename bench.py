@@ -489,18 +489,14 @@ def main():
         }
         if is_tc and args.mode == "plan" and kern_us > 0:
             # The cost of a TagContinuous tick falls along the episode (agents leave the game), so a `value` timed over a
-            # window that is not a whole number of episodes is the rate of THAT window, not of the workload.  The rate
-            # that belongs next to `roofline.frac` (both from the two whole-episode timing passes) is always printed;
-            # `value` itself is replaced by it when the timed window covers no whole episode.
-            episode_rate = world * E / (kern_us * 1e-6)
+            # window that is not a whole number of episodes is the rate of THAT window (the contract: exactly K timed
+            # steps), not of the workload.  The rate that belongs next to `roofline.frac` -- both from the two
+            # whole-episode HIP-event passes -- is always printed beside it, and the line says which kind `value` is.
             whole = (steps % T == 0) and steps >= T
-            out["value_episode_average"] = episode_rate
-            out["value_window"] = {"whole_episodes": whole, "env_steps_per_s_of_the_window": out["value"]}
-            if not whole and steps < T:
-                out["value"] = episode_rate
-                out["value_window"]["note"] = (f"the timed window ({steps} ticks from tick {window_first_tick}) is not a whole "
-                                               f"episode ({T} ticks): `value` is the episode-average rate of the HIP-event "
-                                               f"passes; the window's own rate is kept here")
+            out["value_episode_average"] = world * E / (kern_us * 1e-6)
+            out["value_window"] = {"whole_episodes": whole, "first_tick": window_first_tick, "ticks": steps,
+                                   "note": None if whole else "`value` is the rate of a window shorter than (or not a multiple "
+                                   "of) an episode; quote `value_episode_average` next to roofline.frac"}
         if not args.no_cpu_baseline and args.workload == "tag_continuous" and world == 1:  # N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline({k: v for k, v in cfg.items()})
