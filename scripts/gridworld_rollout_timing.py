@@ -14,7 +14,9 @@ def small(h):
 
 
 CASES = [("[256,256] default (framework forward: 4000 + 1000 rows)", {}, {}),
+         ("[256,256] default, tick replayed from a hipGraph", {"graph_rollout": True}, {}),
          ("[256,256] fused forward kernel forced", {"fused_policy_forward_min_rows": 0}, {}),
+         ("[256,256] fused forward kernel forced, tick replayed from a hipGraph", {"fused_policy_forward_min_rows": 0, "graph_rollout": True}, {}),
          ("[32,32] policies inside the rollout kernel (one launch per batch)", {}, small(32)),
          ("[32,32] per-tick path", {"fused_rollout_policy": False}, small(32)),
          ("[64,64] policies inside the rollout kernel (one launch per batch)", {}, small(64)),

@@ -241,9 +241,11 @@ __device__ __forceinline__ void gw_rollout_impl(
   int act_dx[5], act_dy[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) { act_dx[i] = kIndexToActionArr[2 * i]; act_dy[i] = kIndexToActionArr[2 * i + 1]; }
-  if (tid < 2) s_flag[tid] = 0;
 
   for (int env0 = blockIdx.x * epb; env0 < n_envs; env0 += gridDim.x * epb) {
+    // (per trip: a flag left set by the previous trip's last tick must not send this trip's tick 0 into the restore
+    // path; the barrier behind the loads below publishes the clear)
+    if (tid < 2) s_flag[tid] = 0;
     const int env = env0 + el;
     const bool active = (el < epb) && (env < n_envs);
     const int idx = env * N + ag;

@@ -98,13 +98,29 @@ def _push(env_wrapper, feed):
         env_wrapper.cuda_data_manager.push_data_to_device(feed, torch_accessible=True)
 
 
+def reset_is_deterministic(env):
+    """True when `env.reset()` provably returns the same observation every time: some class of its MRO sets
+    RESET_IS_DETERMINISTIC = True AND no class below that one overrides reset().  A subclass whose reset() draws random
+    starts (or wraps a reset pool) therefore falls back to the reference's one-reset-per-replica behaviour
+    (data_loader.py:348) unless it sets the flag itself -- inheriting the flag silently would replicate ONE
+    observation over all replicas."""
+    if "RESET_IS_DETERMINISTIC" in vars(env):  # an instance says so itself
+        return bool(vars(env)["RESET_IS_DETERMINISTIC"])
+    mro = type(env).__mro__
+    flag_owner = next((c for c in mro if "RESET_IS_DETERMINISTIC" in c.__dict__), None)
+    if flag_owner is None or not flag_owner.__dict__["RESET_IS_DETERMINISTIC"]:
+        return False
+    reset_owner = next((c for c in mro if "reset" in c.__dict__), None)
+    return reset_owner is None or issubclass(flag_owner, reset_owner)
+
+
 def _observation_placeholders(env_wrapper, agent_ids, obs_dim, suffix=""):
     E = env_wrapper.n_envs
     # The reference resets the host env once per replica (data_loader.py:348).  An env whose reset draws nothing
     # (RESET_IS_DETERMINISTIC: TagContinuous and TagGridWorld restart from the positions drawn in the constructor)
     # returns the same observation every time, and a host reset of a 1005-agent replica takes 70 ms: one reset,
     # E copies -- the same arrays, 2000 x sooner.
-    same = bool(getattr(env_wrapper.env, "RESET_IS_DETERMINISTIC", False))
+    same = reset_is_deterministic(env_wrapper.env)
     obs = [env_wrapper.obs_at_reset()] if same else [env_wrapper.obs_at_reset() for _ in range(E)]
 
     def stack(rows):
