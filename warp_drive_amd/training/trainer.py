@@ -192,7 +192,13 @@ class Trainer:
         self._b_rows = torch.zeros(E, dtype=torch.long, device=self.device)
         self._b_idx = self._b_rows[:1]
         self._tick_graph = None
-        self._want_graph = bool(tcfg.get("graph_rollout", False)) and self.engine.fused
+        # "auto": where the tick is bound by the host's ~70 framework dispatches rather than by the GPU -- few observation
+        # rows per tick (TagGridWorld at configs[1]: 5 000 rows, 386 -> 132 us per tick when replayed from a graph;
+        # TagContinuous at configs[2], 210 000 rows, is GPU-bound: no difference)
+        want = tcfg.get("graph_rollout", "auto")
+        if isinstance(want, str):
+            want = want.lower() == "true" or (want.lower() == "auto" and E * env_wrapper.n_agents <= 50000)
+        self._want_graph = bool(want) and self.engine.fused
         # precision of the policy forward in the ROLLOUT (the update always runs in float32, as the
         # reference): "float32" (default, reference semantics) or "bfloat16" (the MLP's GEMMs on the
         # bf16 matrix cores; the sampler still reads float32 probabilities)
