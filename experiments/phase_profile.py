@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
-"""Per-wavefront phase timeline of the fused TagContinuous tick (variant "prof" of
-experiments/variant_sets.py = the product source built with -DWD_TC_PROBES: shader-clock stamps at the phase
-boundaries + counters of the search's fallbacks, written through a __device__ pointer the harness sets).  Run on the GPU box after `variants.py build profile`:
-    python experiments/phase_profile.py [variant-name] [num_envs] [episode tick of the stamped launch]"""
+"""Per-wavefront phase timeline of the fused TagContinuous tick: the kernel source built with -DWD_TC_PROBES (shader-clock
+stamps at the phase boundaries + counters of the search's fallbacks, written through a __device__ pointer the harness
+sets).  Build the stamped code object here (hipcc cross-compiles), run on the GPU box:
+    python experiments/phase_profile.py build
+    python experiments/phase_profile.py [num_envs] [episode tick of the stamped launch] [runners per replica]
+The stamped object replaces the product's through WD_HSACO_DIR (build/variants/prof/), everything else is the product."""
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-name = sys.argv[1] if len(sys.argv) > 1 else "prof"
-E = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-T_STAMP = int(sys.argv[3]) if len(sys.argv) > 3 else 300  # (episodes are 500 ticks; the live-agent count falls along them)
-N_RUNNERS = int(sys.argv[4]) if len(sys.argv) > 4 else 100  # 5 taggers + this many runners per replica
-os.environ["WD_HSACO"] = os.path.join(ROOT, "build", "variants", f"{name}.hsaco")
+PROF_DIR = os.path.join(ROOT, "build", "variants", "prof")
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    from warp_drive_amd import build as wb
+
+    os.makedirs(PROF_DIR, exist_ok=True)
+    for out, (unit, flags) in wb.UNITS.items():
+        if out.startswith("wd_kernels_tc_k10"):  # the headline entry and the runtime-size K = 10 entries (big replicas)
+            subprocess.run([wb._hipcc(), *wb.KERNEL_FLAGS, *flags, "-DWD_TC_PROBES=1", os.path.join(wb.KDIR, unit), "-o",
+                            os.path.join(PROF_DIR, out)], check=True)
+            print("built", os.path.join(PROF_DIR, out))
+    sys.exit(0)
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+T_STAMP = int(sys.argv[2]) if len(sys.argv) > 2 else 300  # (episodes are 500 ticks; the live-agent count falls along them)
+N_RUNNERS = int(sys.argv[3]) if len(sys.argv) > 3 else 100  # 5 taggers + this many runners per replica
+name = "prof"
+os.environ["WD_HSACO_DIR"] = PROF_DIR
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import time
 
@@ -39,7 +53,7 @@ SLOTS = 24
 n_waves = WPB * E
 buf = drv.mem_alloc(n_waves * SLOTS * 8)
 drv.memset(buf, 0, n_waves * SLOTS * 8)
-sym, nbytes = w.cuda_function_manager._module.get_global("tc_prof_g")
+sym, nbytes = w.cuda_function_manager._module_of(engine.step_kernel_name).get_global("tc_prof_g")  # the stamped object
 drv.memcpy_htod(sym, np.array([int(buf)], dtype=np.uint64))
 engine.run(300)
 torch.cuda.synchronize()
