@@ -424,3 +424,66 @@ def test_relu_backward_with_column_sums(R, C):
     want = torch.ops.aten.threshold_backward(g, y, 0)
     assert torch.equal(got, want)
     assert torch.allclose(sums, want.sum(0), rtol=1e-5, atol=1e-4)
+
+
+def test_update_from_stored_rollout_activations(tmp_path):
+    """`trainer.reuse_rollout_activations`: the rollout's forward kernel stores the hidden activations and the outputs of
+    every batch row and the update's forward pass is a read of them.  Against the update that recomputes its forward
+    pass (framework GEMMs) on the SAME batch and weights: the stored tensors equal the recomputed ones to float32
+    rounding (the outputs up to the per-head shift, which softmax does not see), the loss to 1e-5 relative and every
+    parameter's gradient to 1e-4 of its largest entry; and after two training iterations of both trainers the weights
+    still agree closely (same rollouts: the sampled actions do not depend on the switch)."""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.training.scripts.train import setup_trainer
+
+    require_gpu()
+    ov = {"trainer": {"num_envs": 29, "train_batch_size": 29 * 10, "num_episodes": 4000, "seed": 3,
+                      "fused_policy_forward_min_rows": 0},
+          "env": {"num_runners": 40, "episode_length": 8, "num_other_agents_observed": 10},
+          "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
+    trainers = {}
+    for reuse in (True, False):
+        torch.manual_seed(0)
+        ov["trainer"]["reuse_rollout_activations"] = reuse
+        tr = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"s{int(reuse)}"), verbose=False)
+        assert (tr._stored is not None) == reuse and tr._fast_tick is not None
+        trainers[reuse] = tr
+    a, b = trainers[True], trainers[False]
+    for tr in (a, b):
+        tr._generate_rollout_batch()
+    torch.cuda.synchronize()
+    assert a._rollout_filled_stored and not b._rollout_filled_stored
+    for pol in a.policies:
+        assert torch.equal(a.batch[pol]["obs"], b.batch[pol]["obs"]) and torch.equal(a.batch[pol]["actions"], b.batch[pol]["actions"])
+        h1, h2, out = a._stored[pol]
+        model = b.models[pol]
+        with torch.no_grad():
+            x = b.batch[pol]["obs"][: b.batch_len]
+            r1 = torch.relu(model.fc["0"][0](x))
+            r2 = torch.relu(model.fc["1"][0](r1))
+            ref = model.forward_logits(x)
+        assert torch.allclose(h1, r1, rtol=1e-5, atol=2e-6) and torch.allclose(h2, r2, rtol=1e-5, atol=2e-6)
+        start = 0
+        for A in a.head_sizes:  # per head: stored = logits - max(logits)
+            z = ref[..., start:start + A]
+            assert torch.allclose(out[..., start:start + A], z - z.max(dim=-1, keepdim=True).values, rtol=1e-5, atol=5e-6)
+            start += A
+        assert torch.allclose(out[..., start], ref[..., start], rtol=1e-5, atol=5e-6)
+    grads = {}
+    for name, tr in (("stored", a), ("recomputed", b)):
+        tr.grad_bucket.zero()
+        metrics = tr._update_model_params(0, True)
+        grads[name] = ({pol: [p.grad.detach().clone() for p in tr.models[pol].parameters()] for pol in tr.policies}, metrics)
+    for pol in a.policies:
+        la, lb = grads["stored"][1][pol]["Total loss"], grads["recomputed"][1][pol]["Total loss"]
+        assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (pol, la, lb)
+        # (the optimizer has stepped inside _update_model_params: compare what it stepped with)
+        for ga, gb in zip(grads["stored"][0][pol], grads["recomputed"][0][pol]):
+            assert float((ga - gb).abs().max()) <= 1e-4 * max(float(gb.abs().max()), 1e-6), pol
+    for tr in (a, b):
+        tr.train(2)
+    for pol in a.policies:
+        for pa, pb in zip(a.models[pol].parameters(), b.models[pol].parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-2, atol=2e-3), pol
+    for tr in (a, b):
+        tr.graceful_close()

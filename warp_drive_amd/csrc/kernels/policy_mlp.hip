@@ -124,6 +124,11 @@ struct MlpArgs {
   int *act_out;           // [T, n_rows, 2] training-batch copy, or null
   int stream_tag;
   int tile0;              // first 32-row tile of THIS policy in the launch (several policies share one launch)
+  // ---- what the UPDATE of an on-policy trainer would otherwise recompute (bf16x3 path; null: not stored): row t of
+  // [T, n_rows, H] post-ReLU activations of the two hidden layers and of [T, n_rows, A0 + A1 + 1] outputs (the logits
+  // of each head shifted by the head's maximum -- softmax, log-probabilities and entropy do not see the shift -- then
+  // the value).  The weights do not change between a rollout and its update, so the update's forward pass is a read.
+  float *h1_out, *h2_out, *logits_out;
 };
 
 // ---- what follows the output layer, shared by both arithmetic paths: softmax per head, the actions drawn from the
@@ -149,6 +154,34 @@ __device__ __forceinline__ void mlp_epilogue(const MlpArgs &p, float *lds, mlp_v
   m0 = fmaxf(m0, __shfl_xor(m0, 32));
   m1 = fmaxf(m1, __shfl_xor(m1, 32));
   if (p.A1 == 0) m1 = 0.0f;  // (no second head: keep the arithmetic below finite)
+  constexpr int TS = 65;  // tile stride (odd: conflict-free column writes)
+  __syncthreads();        // every wavefront is done with the weight buffers: the tiles below reuse them
+  float *const tile = lds + wave * (32 * TS + 32);
+  int *const tile_rows = (int *)(tile + 32 * TS);  // destination row of every agent of the tile (-1: none)
+  if (p.logits_out) {
+    // the outputs the update's objective works on: per head the logits minus the head's maximum, then the value; out
+    // through the LDS tile so that every store instruction writes (parts of) whole rows
+#pragma unroll
+    for (int tn = 0; tn < TN3; ++tn)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int r = 32 * tn + mlp_row(s, h);
+        tile[j * TS + r] = acc3[tn][s] - ((r < r1) ? m0 : (r < r2) ? m1 : 0.0f);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int W = r2 + 1, g0 = g - j;  // floats per row; first policy-local row of the tile
+    const long long t = p.batch_row ? p.batch_row[(long)(min(g0, p.n_rows - 1) / p.n_pol) * p.batch_row_stride] : 0;
+    float *const dst = p.logits_out + ((long)t * p.n_rows + g0) * W;  // the tile's 32 rows are contiguous
+    const int n = min(32, p.n_rows - g0) * W;
+    const float inv_w = 1.0f / (float)W;
+    for (int q = lane; q < n; q += 64) {
+      const int a = (int)(((float)q + 0.5f) * inv_w);  // q / W (exact for these sizes)
+      dst[q] = tile[a * TS + (q - a * W)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // (the probabilities overwrite the tile next)
+  }
   float z0 = 0.0f, z1 = 0.0f, value = 0.0f;
 #pragma unroll
   for (int tn = 0; tn < TN3; ++tn)
@@ -171,10 +204,6 @@ __device__ __forceinline__ void mlp_epilogue(const MlpArgs &p, float *lds, mlp_v
   // holds single elements of its agent's rows, and storing them directly is 64 separate 4-byte
   // segments per instruction.  The tile [32 agents][64 rows (+1)] of a wavefront reuses the weight
   // buffers once every wavefront is done with them (the host sizes the LDS for 4 tiles as well).
-  constexpr int TS = 65;  // tile stride (odd: conflict-free column writes)
-  __syncthreads();
-  float *const tile = lds + wave * (32 * TS + 32);
-  int *const tile_rows = (int *)(tile + 32 * TS);  // destination row of every agent of the tile (-1: none)
 #pragma unroll
   for (int tn = 0; tn < TN3; ++tn)
 #pragma unroll
@@ -409,6 +438,21 @@ __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *b
 #undef MLP3_READ
 }
 
+// one layer's post-ReLU activations of this wavefront's 32 agents -> row-major [row][H]: register s of tile tn holds
+// hidden unit 32 tn + (s & 3) + 8 (s >> 2) + 4 h of agent j, so registers 4 q .. 4 q + 3 are 16 contiguous bytes
+// (and the two lane halves of an agent 32): 4 * TN 16-byte stores per lane
+template <int TN>
+__device__ __forceinline__ void mlp_store_activations(float *dst, const mlp_v16 (&acc)[TN], bool valid, int h) {
+  if (!valid) return;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const mlp_v4 v = {acc[tn][4 * q], acc[tn][4 * q + 1], acc[tn][4 * q + 2], acc[tn][4 * q + 3]};
+      *(mlp_v4 *)(dst + 32 * tn + 8 * q + 4 * h) = v;
+    }
+}
+
 template <int TN1, int TN2, int KT1>
 __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   constexpr int TN3 = 2;
@@ -487,6 +531,8 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
     ++c;
   }
   mlp_relu<TN1>(acc1);
+  const long long t_row = (p.h1_out || p.h2_out) && p.batch_row ? p.batch_row[(long)env * p.batch_row_stride] : 0;
+  if (p.h1_out) mlp_store_activations<TN1>(p.h1_out + ((long)t_row * p.n_rows + g) * (32 * TN1), acc1, valid, h);
   mlp_bf8 x2[TN1][3][2];
 #pragma unroll
   for (int t = 0; t < TN1; ++t) mlp_split3(acc1[t], x2[t]);
@@ -498,6 +544,7 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
     ++c;
   }
   mlp_relu<TN2>(acc2);
+  if (p.h2_out) mlp_store_activations<TN2>(p.h2_out + ((long)t_row * p.n_rows + g) * (32 * TN2), acc2, valid, h);
   mlp_bf8 x3[TN2][3][2];
 #pragma unroll
   for (int t = 0; t < TN2; ++t) mlp_split3(acc2[t], x3[t]);
@@ -523,7 +570,8 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.A0 = A0; p.A1 = A1;             \
   p.probs0 = probs0; p.probs1 = probs1; p.values = values; p.obs_out = obs_out; p.batch_row = batch_row; \
   p.batch_row_stride = 0;                                                                              \
-  p.rng_state = nullptr; p.actions = nullptr; p.act_out = nullptr; p.stream_tag = 0; p.tile0 = 0;
+  p.rng_state = nullptr; p.actions = nullptr; p.act_out = nullptr; p.stream_tag = 0; p.tile0 = 0;   \
+  p.h1_out = nullptr; p.h2_out = nullptr; p.logits_out = nullptr;
 
 // HipPolicyMlpAct_*: ALL policies of a rollout tick in ONE launch (blocks [0, first_block_b) serve policy A, the rest
 // policy B; first_block_b >= gridDim.x: one policy) with the actions drawn in the epilogue: the probabilities never
@@ -535,8 +583,10 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
       uint32_t *rng_state, int *actions, int stream_tag, int first_block_b,                           \
       const int *a_agent_ids, int a_id0, int a_n_pol, int a_n_rows, const float *a_w1, const float *a_b1, \
       const float *a_w2, const float *a_b2, const float *a_w3, const float *a_b3, float *a_obs_out, int *a_act_out, \
+      float *a_h1_out, float *a_h2_out, float *a_logits_out,                                          \
       const int *b_agent_ids, int b_id0, int b_n_pol, int b_n_rows, const float *b_w1, const float *b_b1, \
-      const float *b_w2, const float *b_b2, const float *b_w3, const float *b_b3, float *b_obs_out, int *b_act_out
+      const float *b_w2, const float *b_b2, const float *b_w3, const float *b_b3, float *b_obs_out, int *b_act_out, \
+      float *b_h1_out, float *b_h2_out, float *b_logits_out
 #define WD_MLP_ACT_PACK()                                                                             \
   const bool second = (int)blockIdx.x >= first_block_b; /* block-uniform: scalar selects */           \
   MlpArgs p;                                                                                          \
@@ -547,7 +597,9 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   p.n_pol = second ? b_n_pol : a_n_pol; p.n_rows = second ? b_n_rows : a_n_rows;                      \
   p.w1 = second ? b_w1 : a_w1; p.b1 = second ? b_b1 : a_b1; p.w2 = second ? b_w2 : a_w2;              \
   p.b2 = second ? b_b2 : a_b2; p.w3 = second ? b_w3 : a_w3; p.b3 = second ? b_b3 : a_b3;              \
-  p.obs_out = second ? b_obs_out : a_obs_out; p.act_out = second ? b_act_out : a_act_out;
+  p.obs_out = second ? b_obs_out : a_obs_out; p.act_out = second ? b_act_out : a_act_out;            \
+  p.h1_out = second ? b_h1_out : a_h1_out; p.h2_out = second ? b_h2_out : a_h2_out;                   \
+  p.logits_out = second ? b_logits_out : a_logits_out;
 
 extern "C" {
 // HipPolicyMlp_<H1>x<H2>_k<KT1>: hidden widths H1, H2; observation rows of up to 32 * KT1 floats.

@@ -89,6 +89,18 @@ class FullyConnected(nn.Module):
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
         return _Affine.apply(x, w, b, False)
 
+    def forward_logits_stored(self, obs, h1, h2, out):
+        """`forward_logits` without arithmetic: the rollout's forward kernel stored the hidden activations and the outputs
+        of exactly these rows under exactly these weights (on-policy: nothing changed them since), so the forward pass is
+        a read and only the backward runs (training/policy_kernel.py::FusedRolloutTick `stored`).  Two hidden layers."""
+        assert len(self.fc) == 2
+        l1, l2 = self.fc["0"][0], self.fc["1"][0]
+        x = _AffineStored.apply(obs, l1.weight, l1.bias, True, h1)
+        x = _AffineStored.apply(x, l2.weight, l2.bias, True, h2)
+        w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
+        b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
+        return _AffineStored.apply(x, w, b, False, out)
+
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
         """The same network for the ROLLOUT (no autograd): bias + ReLU fused into the trunk GEMMs'
@@ -178,6 +190,24 @@ class _Affine(torch.autograd.Function):
             if gb is None:
                 gb = _column_sums(g2)
         return gx, gw, gb, None
+
+
+class _AffineStored(torch.autograd.Function):
+    """`_Affine` whose forward result is already known (`y_stored`, same shape as the output): nothing is computed going
+    forward; the backward is `_Affine`'s, on the stored activations (float32 only)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, y_stored):
+        x2 = x.reshape(-1, x.shape[-1])
+        y2 = y_stored.reshape(-1, w.shape[0])
+        assert x2.dtype == torch.float32 and y2.dtype == torch.float32 and x2.shape[0] == y2.shape[0]
+        ctx.save_for_backward(x2, w, y2 if relu else x2.new_empty(0))
+        ctx.relu, ctx.in_shape = bool(relu), x.shape
+        return y_stored.view(*x.shape[:-1], w.shape[0])  # (a view: the stored rows are not copied)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (*_Affine.backward(ctx, g), None)
 
 
 _FUSED_EPILOGUE = {"ok": hasattr(torch, "_addmm_activation")}  # decided once: a private torch entry point

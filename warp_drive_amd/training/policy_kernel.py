@@ -181,7 +181,11 @@ class FusedRolloutTick:
     host-side indices, so a tick can be captured in a hipGraph."""
 
     def __init__(self, function_manager, forwards, agent_ids, obs, actions, rewards, done, rng_state, stream_tag,
-                 batch_row, obs_batches, action_batches, reward_batches, done_batch, ep_rewards, ep_sums, ep_count):
+                 batch_row, obs_batches, action_batches, reward_batches, done_batch, ep_rewards, ep_sums, ep_count,
+                 stored=None):
+        """stored (optional): per policy None or (h1 [T, E, n_pol, H], h2 [T, E, n_pol, H], out [T, E, n_pol, A0 + A1 + 1])
+        float32 -- the forward launch also writes row t of the hidden activations and of the outputs, which is all the
+        update's forward pass would recompute (bf16x3 arithmetic only)."""
         assert 1 <= len(forwards) <= 2
         f0 = forwards[0]
         assert all((f.H, f.kt1, f.heads, f.F) == (f0.H, f0.kt1, f0.heads, f0.F) for f in forwards), \
@@ -210,12 +214,20 @@ class FusedRolloutTick:
             for t, shape in ((obs_batches[k], (E, n_pol, F)), (action_batches[k], (E, n_pol, 2)), (reward_batches[k], (E, n_pol))):
                 assert t.is_contiguous() and tuple(t.shape[1:]) == shape, (tuple(t.shape), shape)
             assert action_batches[k].dtype == torch.int32
+            extra = [null, null, null]
+            if stored is not None and stored[k] is not None:
+                assert f.bx3, "the activations are stored by the bf16x3 kernel"
+                h1, h2, out = stored[k]
+                W = sum(f.heads) + 1
+                for t, shape in ((h1, (E, n_pol, f.H)), (h2, (E, n_pol, f.H)), (out, (E, n_pol, W))):
+                    assert t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape[1:]) == shape, (tuple(t.shape), shape)
+                extra = [h1, h2, out]
             per_policy.append([null if contiguous else ids32, np.int32(ids_host[0]), np.int32(n_pol), np.int32(n_rows),
-                               *f.packed, obs_batches[k], action_batches[k]])
+                               *f.packed, obs_batches[k], action_batches[k], *extra])
             self._keep = getattr(self, "_keep", []) + [ids32]
         assert (slot >= 0).all(), "every agent belongs to exactly one policy of the launch"
         if len(forwards) == 1:
-            per_policy.append([null, np.int32(0), np.int32(1), np.int32(0)] + [null] * 8)
+            per_policy.append([null, np.int32(0), np.int32(1), np.int32(0)] + [null] * 11)
         self.slot = torch.from_numpy(slot.astype(np.int32)).to(dev)
         assert batch_row.dtype == torch.int64 and batch_row.numel() == E
         self.fwd_args = [obs, np.int32(F), np.int32(N), np.int32(f0.heads[0]), np.int32(f0.heads[1]), null, null, batch_row,

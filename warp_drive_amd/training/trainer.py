@@ -229,6 +229,7 @@ class Trainer:
         # (training/policy_kernel.py::FusedRolloutTick).  Needs: every policy on the fused forward with one network
         # shape, a two-head action space, and an env with a step + reset entry for given actions.
         self._fast_tick = None
+        self._stored, self._rollout_filled_stored = None, False
         fw = [self._fused_forward[pol] for pol in self.policies]
         if (bool(tcfg.get("fused_tick", True)) and all(f is not None for f in fw) and len(fw) <= 2 and self.engine.fused
                 and len(self.head_sizes) == 2 and self.batch_len > 1 and self.actions.dtype == torch.int32
@@ -236,13 +237,34 @@ class Trainer:
                 and all((f.H, f.kt1, f.heads) == (fw[0].H, fw[0].kt1, fw[0].heads) for f in fw)):
             from warp_drive_amd.managers.function_manager import _stream_tag
 
+            # `trainer.reuse_rollout_activations` (default on; float32 update, bf16x3 forward): the forward launch also
+            # stores the hidden activations and outputs of every batch row -- 2 x [T, rows, 256] + [T, rows, 43] float32
+            # per policy, 22 GB at configs[2] of the GPU's 288 -- and the update's forward pass becomes a read of them
+            # (on-policy: the weights have not changed in between).  Off when the buffers would take more than half of
+            # the free memory.
+            self._stored = None
+            if (bool(tcfg.get("reuse_rollout_activations", True)) and self._update_dtype is None and self._fused_update
+                    and all(f.bx3 for f in fw) and all(len(self.models[pol].fc) == 2 for pol in self.policies)):
+                W = sum(self.head_sizes) + 1
+                need = sum(4 * self.batch_len * E * len(self.policy_map[pol]) * (2 * fw[0].H + W) for pol in self.policies)
+                free = torch.cuda.mem_get_info(self.device)[0]
+                if need <= free // 2:
+                    self._stored = {}
+                    for pol in self.policies:
+                        n = len(self.policy_map[pol])
+                        self._stored[pol] = tuple(torch.empty((self.batch_len, E, n, c), dtype=torch.float32, device=self.device)
+                                                  for c in (fw[0].H, fw[0].H, W)) if config["policy"][pol]["to_train"] else None
+                else:
+                    logging.warning(f"reuse_rollout_activations: {need / 2**30:.1f} GiB of buffers do not fit half of the free "
+                                    f"memory ({free / 2**30:.1f} GiB); the update recomputes its forward pass")
             self._fast_tick = FusedRolloutTick(
                 env_wrapper.cuda_function_manager, fw, [self.ids[pol] for pol in self.policies],
                 self.obs.reshape(E, N, -1), self.actions, self.rewards, self.done, self.sampler.rng_state,
                 _stream_tag("tick"), self._b_rows, [self.batch[pol]["obs"] for pol in self.policies],
                 [self.batch[pol]["actions"] for pol in self.policies], [self.batch[pol]["rewards"] for pol in self.policies],
                 self.done_batch, [self._ep_reward[pol] for pol in self.policies],
-                [self._ep_sum[pol] for pol in self.policies], self._ep_cnt)
+                [self._ep_sum[pol] for pol in self.policies], self._ep_cnt,
+                stored=None if self._stored is None else [self._stored[pol] for pol in self.policies])
             self._presampled_engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
                                                     presampled_actions=True)
         # ---- whole-batch rollout in ONE launch: envs whose tick kernel can evaluate small policies itself (Cartpole:
@@ -420,6 +442,8 @@ class Trainer:
                 self._tick_graph.replay()
             else:
                 self._tick()
+        # (the stored activations belong to THIS batch and to the weights it was rolled out with)
+        self._rollout_filled_stored = self._fast_tick is not None and getattr(self, "_stored", None) is not None
 
     # ---------------------------------------------------------------------------- update
     def _update_model_params(self, iteration, log):
@@ -434,9 +458,14 @@ class Trainer:
             if self._fused_update and self.neg_pos_env_ratio <= 0:
                 # the objective and its gradient with respect to the network's output as ONE kernel, the ReLU masks and
                 # bias gradients of the backward as one pass each (training/update_kernels.py); the GEMMs are the framework's
-                with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
-                                    enabled=self._update_dtype is not None):
-                    out = self.models[pol].forward_logits(batch["obs"][: self.batch_len])
+                stored = getattr(self, "_stored", None)
+                if stored is not None and stored.get(pol) is not None and self._rollout_filled_stored:
+                    # the forward pass is a read: the rollout's forward kernel stored these rows' activations and outputs
+                    out = self.models[pol].forward_logits_stored(batch["obs"][: self.batch_len], *stored[pol])
+                else:
+                    with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
+                                        enabled=self._update_dtype is not None):
+                        out = self.models[pol].forward_logits(batch["obs"][: self.batch_len])
                 loss, m = self.trainers[pol].compute_loss_and_metrics_from_logits(
                     self.current_timestep[pol], out.float(), batch["actions"][: self.batch_len],
                     batch["rewards"][: self.batch_len], done[: self.batch_len], self.head_sizes, log)
