@@ -4,14 +4,16 @@ semantics) vs bf16-autocast update.  Run on the GPU box; the output is kept as p
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from warp_drive_amd.training.scripts.train import setup_trainer
-CASES = [("float32", "float32", True, True, "bf16x3"), ("float32", "float32", True, True, "float32"),
+CASES = [("float32", "float32", True, True, "bf16x3"), ("float32", "float32", True, True, "bf16x3-no-reuse"),
+         ("float32", "float32", True, True, "float32"),
          ("float32", "float32", True, False, "float32"), ("bfloat16", "float32", True, True, "bf16x3"),
          ("bfloat16", "bfloat16", False, False, "float32")]
 if len(sys.argv) > 1:
     CASES = CASES[: int(sys.argv[1])]
 for update, rollout, fused, fast, arith in CASES:
     ov = {"trainer": {"num_envs": 2000, "train_batch_size": 100000, "rollout_dtype": rollout, "update_dtype": update,
-                      "fused_policy_forward": fused, "fused_tick": fast, "policy_arithmetic": arith}}
+                      "fused_policy_forward": fused, "fused_tick": fast, "policy_arithmetic": arith.split("-")[0],
+                      "reuse_rollout_activations": "no-reuse" not in arith}}
     tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt_{update}_{rollout}_{int(fused)}_{int(fast)}_{arith}", verbose=False)
     tr._generate_rollout_batch(); torch.cuda.synchronize()
     t0 = time.perf_counter()

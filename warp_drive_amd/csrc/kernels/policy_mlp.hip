@@ -407,9 +407,11 @@ __device__ __forceinline__ void mlp_fetch_kb(float *buf, const float *src, int p
 // three-term split `b` of this k-tile's activations.  Output tiles in PAIRS (MFMAs alternate between two accumulators:
 // an instruction between two MFMAs on the same accumulator costs ~43 cycles, between different ones ~6); the LDS
 // operand reads of the next pair are issued before the MFMAs of the current one.  `sync` runs after the first pair.
-template <int TN, typename Sync>
+// `fill` runs inside the scheduling region of the first pair's MFMAs: independent VALU / store work (the NEXT k-tile's
+// activation split) that the matrix pipe's 32-cycle issue gaps absorb.
+template <int TN, typename Sync, typename Fill>
 __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *buf, const mlp_bf8 (&b)[3][2], int lane,
-                                              Sync sync) {
+                                              Sync sync, Fill fill) {
   constexpr int G = TN < 2 ? 1 : 2, NG = TN / G;
   const mlp_bf8 *const w = (const mlp_bf8 *)buf;  // [term][tn][k half][lane]
   mlp_bf8 a[2][G][3][2];
@@ -423,6 +425,7 @@ __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *b
   for (int gi = 0; gi < NG; ++gi) {
     if (gi + 1 < NG) MLP3_READ(gi + 1)
     __builtin_amdgcn_sched_barrier(0);
+    if (gi == 0) fill();
     // (w term, x term) in ascending size of the partial product: lo x hi, hi x lo, mid x mid, mid x hi, hi x mid, hi x hi
     constexpr int WT[6] = {2, 0, 1, 1, 0, 0}, XT[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -465,14 +468,19 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   const int env = gc / p.n_pol, ag = gc - env * p.n_pol;
   const long src_row = (long)env * p.N + (p.agent_ids ? p.agent_ids[ag] : p.id0 + ag);
 
-  // the chunk stream: KT1 k-tiles of layer 1, TN1 of layer 2, TN2 of the output layer; chunk c lives in buffer c % 3
-  constexpr int NC = KT1 + TN1 + TN2;
+  // the chunk stream: KT1 k-tiles of layer 1, TN1 of layer 2, then the output layer's TN2 k-tiles KG at a time (its
+  // k-tiles are only TN3 = 2 output tiles wide: one per chunk would put a hand-over after every 24 MFMAs); chunk c lives
+  // in buffer c % 3
+  constexpr int KG = (TNMAX / TN3 < TN2) ? TNMAX / TN3 : TN2;  // output-layer k-tiles per chunk (they fill a buffer)
+  static_assert(TN2 % KG == 0, "the output layer's k-tiles split evenly into chunks");
+  constexpr int NC = KT1 + TN1 + TN2 / KG;
   int c = 0;  // (compile-time after unrolling)
   auto chunk_src = [&](int cc) -> const float * {
     return cc < KT1 ? p.w1 + (size_t)cc * TN1 * 1536
-                    : cc < KT1 + TN1 ? p.w2 + (size_t)(cc - KT1) * TN2 * 1536 : p.w3 + (size_t)(cc - KT1 - TN1) * TN3 * 1536;
+                    : cc < KT1 + TN1 ? p.w2 + (size_t)(cc - KT1) * TN2 * 1536
+                                     : p.w3 + (size_t)(cc - KT1 - TN1) * KG * TN3 * 1536;
   };
-  auto chunk_pieces = [&](int cc) -> int { return 6 * (cc < KT1 ? TN1 : cc < KT1 + TN1 ? TN2 : TN3); };
+  auto chunk_pieces = [&](int cc) -> int { return 6 * (cc < KT1 ? TN1 : cc < KT1 + TN1 ? TN2 : TN3 * KG); };
   auto buffer = [&](int cc) -> float * { return lds + (cc % 3) * CHUNK; };
 
   mlp_fetch_kb(buffer(0), chunk_src(0), chunk_pieces(0), wave, lane);
@@ -524,36 +532,50 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
 
   mlp_v16 acc1[TN1], acc2[TN2], acc3[TN3];
   // ---- layer 1
+  const auto nothing = [] {};
   mlp_init<TN1>(acc1, p.b1, h);
 #pragma unroll
   for (int kt = 0; kt < KT1; ++kt) {
-    mlp_chunk_bx3<TN1>(acc1, buffer(c), x1[kt], lane, sync);
+    mlp_chunk_bx3<TN1>(acc1, buffer(c), x1[kt], lane, sync, nothing);
     ++c;
   }
-  mlp_relu<TN1>(acc1);
-  const long long t_row = (p.h1_out || p.h2_out) && p.batch_row ? p.batch_row[(long)env * p.batch_row_stride] : 0;
-  if (p.h1_out) mlp_store_activations<TN1>(p.h1_out + ((long)t_row * p.n_rows + g) * (32 * TN1), acc1, valid, h);
-  mlp_bf8 x2[TN1][3][2];
+  // ---- layers 2 and 3 consume the previous layer's activations one 32-row tile (= one k-tile) at a time: tile kt + 1
+  // is ReLU'd and split into its three bf16 terms INSIDE the MFMAs of chunk kt (the matrix pipe's issue gaps absorb the
+  // VALU work); only tile 0 of a layer is prepared in the open.  The ReLU'd activations stay in their accumulator
+  // registers: when the update wants them (h1_out / h2_out) they are stored after the LAST hand-over of the kernel --
+  // every hand-over waits on vmcnt(0), which counts stores too, so a store issued earlier would be waited for (measured:
+  // stores spread over the layers cost as much as one burst, +90 us per tick); after the last one nothing waits and
+  // the 66 MB a round of blocks writes drains under the epilogue and the next block's first layer.
+  mlp_bf8 xs[2][3][2];  // the current and the next tile's split
+  auto prepare = [&](mlp_v16 &tile, mlp_bf8 (&out)[3][2]) {
 #pragma unroll
-  for (int t = 0; t < TN1; ++t) mlp_split3(acc1[t], x2[t]);
+    for (int r = 0; r < 16; ++r) tile[r] = fmaxf(tile[r], 0.0f);
+    mlp_split3(tile, out);
+  };
   // ---- layer 2
   mlp_init<TN2>(acc2, p.b2, h);
+  prepare(acc1[0], xs[0]);
 #pragma unroll
   for (int kt = 0; kt < TN1; ++kt) {
-    mlp_chunk_bx3<TN2>(acc2, buffer(c), x2[kt], lane, sync);
+    mlp_chunk_bx3<TN2>(acc2, buffer(c), xs[kt & 1], lane, sync,
+                       [&] { if (kt + 1 < TN1) prepare(acc1[kt + 1], xs[(kt + 1) & 1]); });
     ++c;
   }
-  mlp_relu<TN2>(acc2);
-  if (p.h2_out) mlp_store_activations<TN2>(p.h2_out + ((long)t_row * p.n_rows + g) * (32 * TN2), acc2, valid, h);
-  mlp_bf8 x3[TN2][3][2];
-#pragma unroll
-  for (int t = 0; t < TN2; ++t) mlp_split3(acc2[t], x3[t]);
   // ---- output layer
   mlp_init<TN3>(acc3, p.b3, h);
+  prepare(acc2[0], xs[0]);
 #pragma unroll
   for (int kt = 0; kt < TN2; ++kt) {
-    mlp_chunk_bx3<TN3>(acc3, buffer(c), x3[kt], lane, sync);
-    ++c;
+    const auto fill = [&] { if (kt + 1 < TN2) prepare(acc2[kt + 1], xs[(kt + 1) & 1]); };
+    const float *const wk = buffer(c) + (kt % KG) * TN3 * 1536;  // this k-tile inside its chunk
+    if (kt % KG == 0) mlp_chunk_bx3<TN3>(acc3, wk, xs[kt & 1], lane, sync, fill);      // (hand-over once per chunk)
+    else mlp_chunk_bx3<TN3>(acc3, wk, xs[kt & 1], lane, nothing, fill);
+    if (kt % KG == KG - 1) ++c;
+  }
+  if (p.h1_out || p.h2_out) {
+    const long long t_row = p.batch_row ? p.batch_row[(long)env * p.batch_row_stride] : 0;
+    if (p.h1_out) mlp_store_activations<TN1>(p.h1_out + ((long)t_row * p.n_rows + g) * (32 * TN1), acc1, valid, h);
+    if (p.h2_out) mlp_store_activations<TN2>(p.h2_out + ((long)t_row * p.n_rows + g) * (32 * TN2), acc2, valid, h);
   }
   mlp_epilogue<TN3>(p, lds, acc3, g, valid, src_row, wave, lane, j, h);
 }
