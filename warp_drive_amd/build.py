@@ -118,9 +118,56 @@ def kernels_in(hsaco):
     return sorted({m.decode() for m in re.findall(rb"\x00([A-Za-z_][A-Za-z0-9_]*)\.kd\x00", blob)})
 
 
+SHAPE_UNIT_PATTERN = re.compile(r"^wd_kernels_tc_k(\d+)_n(\d+)a(\d+)t(\d+)\.hsaco$")
+
+
+def shape_unit_name(k, n_agents, n_actions, threads):
+    return f"wd_kernels_tc_k{int(k)}_n{int(n_agents)}a{int(n_actions)}t{int(threads)}.hsaco"
+
+
+def shape_units_on_disk():
+    """shape-specialised TagContinuous objects built on demand (build_shape_unit): {file name: threads per block}"""
+    found = {}
+    for f in sorted(os.listdir(CSRC)):
+        m = SHAPE_UNIT_PATTERN.match(f)
+        if m:
+            found[f] = int(m.group(4))
+    return found
+
+
+def build_shape_unit(k, n_agents, n_actions, threads, verbose=False):
+    """Build (once, under the build lock) the TagContinuous entries for ONE shape with its sizes and block size as
+    compile-time constants -- what the reference does for every run by templating wkNumberAgents into the source it
+    hands to nvcc (pycuda_function_manager.py:133-232, template_env_config.h:19-21); here it is opt-in
+    (envs/tag_continuous.py: WD_TC_JIT_SHAPES=1), takes one ~15 s hipcc of one unit, and the result is reused by every later
+    run.  Returns the code object's file name; the manifest is rewritten to include its kernels."""
+    import fcntl
+
+    assert 1 <= int(n_agents) <= 128 and int(threads) % 64 == 0
+    out = shape_unit_name(k, n_agents, n_actions, threads)
+    target = os.path.join(CSRC, out)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            srcs = unit_sources("tag_continuous.hip") + [os.path.abspath(__file__)]
+            if not _newer(target, srcs):
+                tmp = target + f".{os.getpid()}.tmp"
+                cmd = [_hipcc(), *KERNEL_FLAGS, f"-DWD_TC_KM={int(k)}", f"-DWD_TC_SHAPE_N={int(n_agents)}",
+                       f"-DWD_TC_SHAPE_A={int(n_actions)}", f"-DWD_TC_SHAPE_THREADS={int(threads)}",
+                       os.path.join(KDIR, "tag_continuous.hip"), "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, target)
+                write_manifest()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
+
+
 def write_manifest():
     manifest = {}
-    for out in UNITS:
+    for out in list(UNITS) + list(shape_units_on_disk()):
         path = os.path.join(CSRC, out)
         if os.path.exists(path):
             for name in kernels_in(path):

@@ -328,17 +328,38 @@ class TagContinuous(CUDAEnvironmentContext):
         # BASELINE shape, 105 agents / K = 10 / 21-way heads); WD_TC_SHAPE_ENTRIES=0 keeps the runtime-size entries
         shaped = f"{default_name}_K{K}_N{self.num_agents}A{len(self.acceleration_actions)}"
         fm = getattr(self, "cuda_function_manager", None)
-        if (self.SHAPE_ENTRIES and len(self.acceleration_actions) == len(self.turn_actions) and fm is not None
-                and fm.has_function(shaped) and self._geometry()[1][0] == self.SHAPE_ENTRY_THREADS.get(shaped, -1)):
-            return shaped
+        if self.SHAPE_ENTRIES and len(self.acceleration_actions) == len(self.turn_actions) and fm is not None:
+            threads = self._geometry()[1][0]
+            if fm.has_function(shaped) and self._shape_entry_threads(fm, shaped) == threads:
+                return shaped
+            if (self.JIT_SHAPE_ENTRIES and self.num_agents <= 128 and K in _K_SPECIALISATIONS and not fm.has_function(shaped)):
+                # opt-in: compile this shape's entries now (one ~15 s hipcc, kept for later runs), as the reference
+                # compiles its templated source for every run (pycuda_function_manager.py:133-232)
+                from warp_drive_amd import build as wd_build
+                from warp_drive_amd.managers import hip_driver as drv
+
+                wd_build.build_shape_unit(K, self.num_agents, len(self.acceleration_actions), threads)
+                drv.reload_manifest()
+                if fm.has_function(shaped) and self._shape_entry_threads(fm, shaped) == threads:
+                    return shaped
         for k in (self._K_SPECIALISATIONS_N1024 if big else _K_SPECIALISATIONS):
             if k >= K:
                 return f"{default_name}_K{k}" + ("_N1024" if big else "_N512" if self.num_agents > 128 else "")
         return default_name
 
     SHAPE_ENTRIES = os.environ.get("WD_TC_SHAPE_ENTRIES", "1") != "0"
-    # threads per block the shape-specialised entries are compiled for (-DWD_TC_SHAPE_THREADS, warp_drive_amd/build.py)
+    # threads per block the prebuilt shape-specialised entries are compiled for (-DWD_TC_SHAPE_THREADS, warp_drive_amd/build.py);
+    # objects built on demand carry theirs in the file name (wd_kernels_tc_k<k>_n<n>a<a>t<threads>.hsaco)
     SHAPE_ENTRY_THREADS = {"HipTagContinuousStep_K10_N105A21": 128}
+    JIT_SHAPE_ENTRIES = os.environ.get("WD_TC_JIT_SHAPES", "0") == "1"
+
+    def _shape_entry_threads(self, fm, entry):
+        if entry in self.SHAPE_ENTRY_THREADS:
+            return self.SHAPE_ENTRY_THREADS[entry]
+        from warp_drive_amd import build as wd_build
+
+        m = wd_build.SHAPE_UNIT_PATTERN.match(os.path.basename(fm.code_object_path_of(entry) or ""))
+        return int(m.group(4)) if m else -1
 
     def lds_bytes(self, epb, fused=False, threads=None):
         """dynamic LDS of HipTagContinuousStep / Tick for `epb` packed replicas (tc_carve_fast /

@@ -48,6 +48,12 @@ def manifest():
     return _manifest
 
 
+def reload_manifest():
+    """forget the cached manifest (a shape-specialised code object was just built: warp_drive_amd.build.build_shape_unit)"""
+    global _manifest
+    _manifest = None
+
+
 def code_object_of(kernel_name):
     """path of the code object that holds `kernel_name`, or None when no object of the build has it"""
     name = manifest().get(kernel_name)
