@@ -203,6 +203,7 @@ class FusedRolloutTick:
         block_rows = f0.WAVES_PER_BLOCK * _WAVE_ROWS
         slot = np.full(N, -1, dtype=np.int64)
         per_policy, blocks = [], []
+        self._id_tables = []  # (the launch arguments hold raw addresses: keep the id tensors alive)
         for k, (f, ids) in enumerate(zip(forwards, agent_ids)):
             ids_host = np.asarray(ids.cpu().numpy(), dtype=np.int64)
             slot[ids_host] = k * 65536 + np.arange(len(ids_host))
@@ -224,7 +225,7 @@ class FusedRolloutTick:
                 extra = [h1, h2, out]
             per_policy.append([null if contiguous else ids32, np.int32(ids_host[0]), np.int32(n_pol), np.int32(n_rows),
                                *f.packed, obs_batches[k], action_batches[k], *extra])
-            self._keep = getattr(self, "_keep", []) + [ids32]
+            self._id_tables.append(ids32)
         assert (slot >= 0).all(), "every agent belongs to exactly one policy of the launch"
         if len(forwards) == 1:
             per_policy.append([null, np.int32(0), np.int32(1), np.int32(0)] + [null] * 11)

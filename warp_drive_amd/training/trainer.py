@@ -443,7 +443,7 @@ class Trainer:
             else:
                 self._tick()
         # (the stored activations belong to THIS batch and to the weights it was rolled out with)
-        self._rollout_filled_stored = self._fast_tick is not None and getattr(self, "_stored", None) is not None
+        self._rollout_filled_stored = self._fast_tick is not None and self._stored is not None
 
     # ---------------------------------------------------------------------------- update
     def _update_model_params(self, iteration, log):
@@ -458,7 +458,7 @@ class Trainer:
             if self._fused_update and self.neg_pos_env_ratio <= 0:
                 # the objective and its gradient with respect to the network's output as ONE kernel, the ReLU masks and
                 # bias gradients of the backward as one pass each (training/update_kernels.py); the GEMMs are the framework's
-                stored = getattr(self, "_stored", None)
+                stored = self._stored
                 if stored is not None and stored.get(pol) is not None and self._rollout_filled_stored:
                     # the forward pass is a read: the rollout's forward kernel stored these rows' activations and outputs
                     out = self.models[pol].forward_logits_stored(batch["obs"][: self.batch_len], *stored[pol])
@@ -484,6 +484,9 @@ class Trainer:
             loss.backward()  # accumulates into this policy's slice of the flat bucket
             if log:
                 metrics[pol] = m
+        # the stored activations belonged to the weights that are about to change: a second update on the same batch (or
+        # anything else before the next rollout) recomputes its forward pass
+        self._rollout_filled_stored = False
         self.grad_bucket.all_reduce_mean()  # ONE collective for all policies (RCCL over xGMI at N > 1)
         for pol in trained:
             pcfg = self.config["policy"][pol]
@@ -565,6 +568,7 @@ class Trainer:
         for pol, path in ckpts_dict.items():
             assert os.path.isfile(path), f"invalid model checkpoint path {path}"
             models[pol].load_state_dict(torch.load(path, map_location=self.device))
+            self._rollout_filled_stored = False  # (activations stored by an earlier rollout belong to the old weights)
             models[pol].refresh_inference_cache()
             stem = os.path.basename(path).split(".state_dict")[0]
             try:
