@@ -487,3 +487,28 @@ def test_update_from_stored_rollout_activations(tmp_path):
             assert torch.allclose(pa, pb, rtol=1e-2, atol=2e-3), pol
     for tr in (a, b):
         tr.graceful_close()
+
+
+@pytest.mark.parametrize("R,W,C", [(10007, 43, 256), (5000, 6, 64), (777, 3, 128)])
+def test_head_backward_kernel(R, W, C):
+    """HipHeadBackward_W<w>: the output layer's backward, the hidden layer's ReLU mask + bias gradient and the output
+    layer's weight gradient in one pass, against the three framework operations it replaces"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training.update_kernels import UpdateKernels
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    k = UpdateKernels(fm)
+    torch.manual_seed(R)
+    g3 = torch.randn(R, W, device="cuda")
+    w3 = torch.randn(W, C, device="cuda") * 0.2
+    h2 = torch.relu(torch.randn(R, C, device="cuda"))
+    assert k.supports_head_backward(g3, w3, h2)
+    g2, db2, dw3 = k.head_backward(g3, w3, h2)
+    ref_g2 = torch.ops.aten.threshold_backward((g3.double() @ w3.double()).float(), h2, 0)
+    assert torch.equal(g2 != 0, ref_g2 != 0) or float(((g2 != 0) != (ref_g2 != 0)).float().mean()) < 1e-6
+    assert torch.allclose(g2, ref_g2, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(db2, ref_g2.double().sum(0).float(), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(dw3, (g3.double().t() @ h2.double()).float(), rtol=1e-4, atol=1e-2)

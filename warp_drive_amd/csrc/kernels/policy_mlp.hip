@@ -623,6 +623,76 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
   p.h1_out = second ? b_h1_out : a_h1_out; p.h2_out = second ? b_h2_out : a_h2_out;                   \
   p.logits_out = second ? b_logits_out : a_logits_out;
 
+namespace {
+
+// HipHeadBackward: the backward of the output layer fused with the ReLU mask of the hidden layer under it.  out = h2 . W3^T
+// + b3 with W3 [W][C] (W = A0 + A1 + 1 <= 64 output rows: all heads' logits and the value; C = 64 / 128 / 256 hidden units)
+// and h2 = relu(...) [R][C].  Given g3 = d loss / d out [R][W]:
+//     g2[r][j]  = [h2[r][j] > 0] * sum_k g3[r][k] W3[k][j]        (the masked gradient the hidden layer's GEMMs consume)
+//     db2[j]    = sum_r g2[r][j]                                   (its bias gradient)
+//     dW3[k][j] = sum_r g3[r][k] h2[r][j]                          (the output layer's weight gradient)
+// in ONE pass: g3 and h2 are read once, g2 is written once.  The framework path is a [R, W] x [W, C] GEMM that writes the
+// unmasked gradient (10 GB at configs[2]), the mask + column-sum pass that reads it back with h2 and writes it again, and
+// a skinny [W, R] x [R, C] GEMM that reads h2 a third time (44 TFLOP/s: W = 43 rows do not fill a tile) -- 15 ms of a
+// 56 ms update for 0.44 TFLOP that the vector units do in the shadow of the 22 GB this kernel moves.
+// One thread per hidden unit (blockDim.x = C): its column of W3 and its 2 W accumulators live in registers; the rows'
+// g3 values reach all threads as LDS broadcasts.  `rows_per_block` rows per block; partial sums per block
+// (`db2_part` [blocks][C], `dw3_part` [blocks][W][C]) are reduced by the caller in a fixed order.
+template <int W>
+__device__ __forceinline__ void head_backward_impl(const float *__restrict__ g3, const float *__restrict__ w3,
+                                                   const float *__restrict__ h2, float *__restrict__ g2,
+                                                   float *__restrict__ db2_part, float *__restrict__ dw3_part, long R,
+                                                   int rows_per_block, float *s_g3) {
+  constexpr int RT = 32;  // rows per staged tile of g3
+  constexpr int WP = (W + 3) & ~3;
+  const int C = blockDim.x, j = threadIdx.x;
+  const long r_begin = (long)blockIdx.x * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+  float wcol[W], dw[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    wcol[k] = w3[(long)k * C + j];
+    dw[k] = 0.0f;
+  }
+  float db = 0.0f;
+  for (long r0 = r_begin; r0 < r_end; r0 += RT) {
+    const int rows = (int)min((long)RT, r_end - r0);
+    __syncthreads();  // (the previous tile is consumed)
+    for (int q = j; q < rows * W; q += C) {  // rows padded to whole 16-byte vectors: the broadcasts below are ds_read_b128
+      const int r = (int)(((float)q + 0.5f) * (1.0f / (float)W));  // q / W (exact for these sizes)
+      s_g3[r * WP + (q - r * W)] = g3[r0 * W + q];
+    }
+    float h[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) h[r] = (r < rows) ? h2[(r0 + r) * C + j] : 0.0f;  // (all loads of the tile in flight)
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < RT; ++r) {
+      if (r >= rows) break;  // block-uniform
+      const float4 *const gv4 = (const float4 *)(s_g3 + r * WP);  // the same address in every lane: LDS broadcasts
+      float gv[WP];
+#pragma unroll
+      for (int q = 0; q < WP / 4; ++q) {
+        const float4 v = gv4[q];
+        gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
+      }
+      float x = 0.0f;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        x = fmaf(gv[k], wcol[k], x);
+        dw[k] = fmaf(gv[k], h[r], dw[k]);
+      }
+      const float m = h[r] > 0.0f ? x : 0.0f;
+      g2[(r0 + r) * C + j] = m;
+      db += m;
+    }
+  }
+  db2_part[(long)blockIdx.x * C + j] = db;
+#pragma unroll
+  for (int k = 0; k < W; ++k) dw3_part[((long)blockIdx.x * W + k) * C + j] = dw[k];
+}
+
+}  // namespace
+
 extern "C" {
 // HipPolicyMlp_<H1>x<H2>_k<KT1>: hidden widths H1, H2; observation rows of up to 32 * KT1 floats.
 // 64, 128 or 256 threads per block (wavefronts x 32 rows), dynamic LDS = max(2 * max(H1, H2) / 32 * 4096,
@@ -815,4 +885,16 @@ __global__ void __launch_bounds__(256) HipReluBackwardColumnSums(const float *__
     partial[(long)blockIdx.x * C + tid] = sum;
   }
 }
+
+#define WD_HEAD_BACKWARD(WW)                                                                                          \
+  __global__ void __launch_bounds__(256) HipHeadBackward_W##WW(const float *g3, const float *w3, const float *h2,     \
+                                                               float *g2, float *db2_part, float *dw3_part, long R,   \
+                                                               int rows_per_block) {                                  \
+    __shared__ __attribute__((aligned(16))) float s_g3[32 * ((WW + 3) & ~3)];                                         \
+    head_backward_impl<WW>(g3, w3, h2, g2, db2_part, dw3_part, R, rows_per_block, s_g3);                              \
+  }
+// (one entry per output width the trainer's configs use: 21 + 21 + 1, 5 + 1, 2 + 1; others take the framework path)
+WD_HEAD_BACKWARD(43)
+WD_HEAD_BACKWARD(6)
+WD_HEAD_BACKWARD(3)
 }

@@ -82,11 +82,15 @@ class FullyConnected(nn.Module):
         """obs [..., obs_size] -> [..., sum(head_sizes) + 1]: the logits of every head, then the value -- what `forward`
         turns into probabilities; the fused objective (training/update_kernels.py) works on this tensor directly"""
         x = obs
-        for i in range(len(self.fc)):
-            lin = self.fc[str(i)][0]
-            x = _Affine.apply(x, lin.weight, lin.bias, True)
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
+        fused_tail = not torch.is_autocast_enabled(obs.device.type) and obs.dtype == torch.float32
+        for i in range(len(self.fc) - (1 if fused_tail else 0)):
+            lin = self.fc[str(i)][0]
+            x = _Affine.apply(x, lin.weight, lin.bias, True)
+        if fused_tail:  # the last hidden layer + the output layer: one node, one backward pass over h2
+            last = self.fc[str(len(self.fc) - 1)][0]
+            return _TailHead.apply(x, last.weight, last.bias, w, b, None, None)
         return _Affine.apply(x, w, b, False)
 
     def forward_logits_stored(self, obs, h1, h2, out):
@@ -96,10 +100,9 @@ class FullyConnected(nn.Module):
         assert len(self.fc) == 2
         l1, l2 = self.fc["0"][0], self.fc["1"][0]
         x = _AffineStored.apply(obs, l1.weight, l1.bias, True, h1)
-        x = _AffineStored.apply(x, l2.weight, l2.bias, True, h2)
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        return _AffineStored.apply(x, w, b, False, out)
+        return _TailHead.apply(x, l2.weight, l2.bias, w, b, h2, out)
 
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
@@ -190,6 +193,42 @@ class _Affine(torch.autograd.Function):
             if gb is None:
                 gb = _column_sums(g2)
         return gx, gw, gb, None
+
+
+class _TailHead(torch.autograd.Function):
+    """The last hidden layer and the output layer as ONE autograd node: h2 = relu(h1 @ W2^T + b2), out = h2 @ W3^T + b3
+    (W3 = all heads' rows, then the value's).  One node so that its backward can run the output layer's backward, the
+    hidden layer's ReLU mask, its bias gradient and the output layer's weight gradient as ONE pass over h2
+    (training/update_kernels.py::head_backward) instead of a GEMM, a mask + column-sum pass and a skinny GEMM that read
+    h2 three times.  `h2_stored` / `out_stored`: the forward results are already known (the rollout stored them):
+    nothing is computed going forward.  float32; the autocast update takes the per-layer `_Affine` path."""
+
+    @staticmethod
+    def forward(ctx, h1, w2, b2, w3, b3, h2_stored, out_stored):
+        h1_2d = h1.reshape(-1, h1.shape[-1])
+        if h2_stored is None:
+            h2 = _linear_relu(h1_2d, w2, b2)
+            out = torch.addmm(b3, h2, w3.t())
+        else:
+            h2, out = h2_stored.reshape(-1, w2.shape[0]), out_stored.reshape(-1, w3.shape[0])
+        ctx.save_for_backward(h1_2d, w2, w3, h2)
+        ctx.in_shape = h1.shape
+        return out.view(*h1.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        h1_2d, w2, w3, h2 = ctx.saved_tensors
+        g3 = g.reshape(-1, g.shape[-1])
+        kernels = update_kernels.active()
+        if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
+            g2, gb2, gw3 = kernels.head_backward(g3, w3, h2)
+        else:
+            g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
+            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
+        gb3 = _column_sums(g3)
+        gw2 = _weight_grad(g2, h1_2d)
+        gh1 = (g2 @ w2).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        return gh1, gw2, gb2, gw3, gb3, None, None
 
 
 class _AffineStored(torch.autograd.Function):

@@ -28,12 +28,14 @@ def install(function_manager):
 
 
 class UpdateKernels:
-    ROWS_PER_BLOCK = 4096   # HipReluBackwardColumnSums: rows per block (a [blocks, C] partial-sum tensor is reduced after it)
+    ROWS_PER_BLOCK = 4096   # rows per block of the passes that leave per-block partial sums (reduced by a framework sum)
+    HEAD_WIDTHS = (43, 6, 3)  # output widths HipHeadBackward_W<w> exists for (21 + 21 + 1, 5 + 1, 2 + 1)
 
     def __init__(self, function_manager):
         names = ["HipPolicyGradientHead", "HipReluBackwardColumnSums"]
         function_manager.initialize_functions(names)
         self.head_fn, self.relu_fn = (function_manager.get_function(n) for n in names)
+        self._fm, self._head_backward_fns = function_manager, {}
 
     # ------------------------------------------------------------------------------------------------ objective
     @staticmethod
@@ -73,6 +75,30 @@ class UpdateKernels:
         self.relu_fn(g, y, out, partial, np.int64(R), np.int32(C), np.int32(self.ROWS_PER_BLOCK),
                      block=(256, 1, 1), grid=(blocks, 1), shared=0)
         return out, partial.sum(dim=0)
+
+
+    # ------------------------------------------------------------------------------------ output layer's backward
+    def supports_head_backward(self, g3, w3, h2):
+        W, C = w3.shape
+        return (g3.is_cuda and g3.dtype == w3.dtype == h2.dtype == torch.float32 and W in self.HEAD_WIDTHS
+                and C in (64, 128, 256) and g3.shape[-1] == W and h2.shape[-1] == C and h2.is_contiguous())
+
+    def head_backward(self, g3, w3, h2):
+        """g3 [R, W] = d loss / d out, w3 [W, C] (all heads' rows, then the value's), h2 [R, C] = relu(...) ->
+        (g2 [R, C] = (g3 @ w3) * [h2 > 0], db2 [C] = its column sums, dw3 [W, C] = g3^T @ h2) in one pass"""
+        R, C = h2.shape
+        W = w3.shape[0]
+        fn = self._head_backward_fns.get(W)
+        if fn is None:
+            self._fm.initialize_functions([f"HipHeadBackward_W{W}"])
+            fn = self._head_backward_fns[W] = self._fm.get_function(f"HipHeadBackward_W{W}")
+        g3, w3 = g3.contiguous(), w3.contiguous()
+        g2 = torch.empty_like(h2)
+        blocks = (R + self.ROWS_PER_BLOCK - 1) // self.ROWS_PER_BLOCK
+        db2 = torch.empty((blocks, C), dtype=torch.float32, device=h2.device)
+        dw3 = torch.empty((blocks, W, C), dtype=torch.float32, device=h2.device)
+        fn(g3, w3, h2, g2, db2, dw3, np.int64(R), np.int32(self.ROWS_PER_BLOCK), block=(C, 1, 1), grid=(blocks, 1), shared=0)
+        return g2, db2.sum(dim=0), dw3.sum(dim=0)
 
 
 class FusedObjective(torch.autograd.Function):
