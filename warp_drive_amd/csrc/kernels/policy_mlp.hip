@@ -759,10 +759,7 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
     *acc = finished ? 0.0f : total;
     if (finished) s_total[a] = total;
   }
-  if (tid == 0) {
-    done_batch[(long)t * n_envs + e] = done[e];
-    batch_row[e] = t + 1;
-  }
+  if (tid == 0) done_batch[(long)t * n_envs + e] = done[e];
   if (finished) {  // block-uniform, once per episode and replica
     __syncthreads();
     if (tid < 2 && (tid == 0 || n_pol_b > 0)) {  // thread p: policy p's agents, in agent order (deterministic sum)
@@ -773,6 +770,10 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
     }
     if (tid == 0) ep_count[e] += 1.0f;
   }
+  // the replica's row counter advances only after EVERY wavefront of the block has read it (a later wavefront of a
+  // multi-wavefront block must not see t + 1)
+  __syncthreads();
+  if (tid == 0) batch_row[e] = t + 1;
 }
 
 // HipPolicyGradientHead: everything between the network's output and its gradient in ONE pass over the batch.  The
