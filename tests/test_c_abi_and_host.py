@@ -242,3 +242,26 @@ def test_kernels_do_not_spill_to_scratch(built, tmp_path):
             limit = 0 if obj in strict else 64
             assert private <= limit and spills <= (0 if obj in strict else 8), (obj, name, private, spills)
     assert seen == len(built.manifest())
+
+
+def test_code_objects_are_a_function_of_source_and_flags_only(built, tmp_path):
+    """The PMC records under profiles/ are keyed by the sha256 of the code object that holds the kernel: a rebuild of
+    unchanged sources -- in another checkout directory, through another output file name -- must give the same bytes
+    (hipcc's default compilation-unit id hashes those paths; warp_drive_amd/build.py passes an explicit -cuid)."""
+    import hashlib
+
+    from warp_drive_amd import build as wd_build
+
+    name = "wd_kernels_tc_k10_n105a21.hsaco"
+    unit, flags = wd_build.UNITS[name]
+    out = tmp_path / "another_name.bin"
+    subprocess.run([wd_build._hipcc(), *wd_build.KERNEL_FLAGS, *wd_build._cuid(name), *flags,
+                    os.path.join(wd_build.KDIR, unit), "-o", str(out)], check=True)
+    sha = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()
+    assert sha(out) == sha(built.code_object_path(name))
+    # ... and that is the object the counters of profiles/ were collected on
+    import json
+
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["E2000"]
+    assert rec["hsaco_sha256"] == sha(built.code_object_path(name)), "profiles/pmc_traffic.json is stale: re-collect (scripts/collect_profiles.sh)"
+    assert json.load(open(os.path.join(ROOT, "profiles", "pmc_mix.json")))["hsaco_sha256"] == rec["hsaco_sha256"]

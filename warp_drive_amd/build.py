@@ -80,6 +80,14 @@ def _newer(target, sources):
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
+def _cuid(code_object_name):
+    """hipcc derives a "compilation unit id" from the paths of the source and of the OUTPUT file and bakes it into the
+    code object: the same source built into another directory -- or through a temporary file name -- is a different
+    file, and the PMC records under profiles/ (keyed by the object's sha256) would go stale with every rebuild.  An
+    explicit id makes the object a function of the source and the flags alone."""
+    return [f"-cuid={os.path.splitext(code_object_name)[0]}"]
+
+
 def _hipcc():
     return shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
 
@@ -152,7 +160,7 @@ def build_shape_unit(k, n_agents, n_actions, threads, verbose=False):
             srcs = unit_sources("tag_continuous.hip") + [os.path.abspath(__file__)]
             if not _newer(target, srcs):
                 tmp = target + f".{os.getpid()}.tmp"
-                cmd = [_hipcc(), *KERNEL_FLAGS, f"-DWD_TC_KM={int(k)}", f"-DWD_TC_SHAPE_N={int(n_agents)}",
+                cmd = [_hipcc(), *KERNEL_FLAGS, *_cuid(out), f"-DWD_TC_KM={int(k)}", f"-DWD_TC_SHAPE_N={int(n_agents)}",
                        f"-DWD_TC_SHAPE_A={int(n_actions)}", f"-DWD_TC_SHAPE_THREADS={int(threads)}",
                        os.path.join(KDIR, "tag_continuous.hip"), "-o", tmp]
                 if verbose:
@@ -189,7 +197,8 @@ def build_kernels(force=False, verbose=False, extra_flags=(), only=None):
         if force or not _newer(target, unit_sources(unit) + [os.path.abspath(__file__)]):
             # compile next to the target and rename: a rank that only reads never sees a half-written object
             tmp = target + f".{os.getpid()}.tmp"
-            jobs.append((target, tmp, [_hipcc(), *KERNEL_FLAGS, *flags, *extra_flags, os.path.join(KDIR, unit), "-o", tmp]))
+            jobs.append((target, tmp, [_hipcc(), *KERNEL_FLAGS, *_cuid(out), *flags, *extra_flags, os.path.join(KDIR, unit),
+                                       "-o", tmp]))
 
     def run(job):
         target, tmp, cmd = job
