@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -156,9 +157,10 @@ def test_device_index_and_backend_override(monkeypatch):
     assert wdd.gather_ints(7) == [7]
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (the driver's N = 1
-    shape of the command); without a GPU the ranks stop at the loud no-GPU assertion, not before"""
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_bench_starts_its_own_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (the driver's N = 1
+    shape of the command; N = 8 = one MI355X node); without a GPU the ranks stop at the loud no-GPU assertion, not before"""
     import subprocess
     import sys
 
@@ -170,7 +172,7 @@ def test_bench_starts_its_own_ranks():
         pytest.skip("covered by tests/test_gpu_multirank.py on a GPU box")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--steps", "2",
                           "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0
     assert "bench.py needs an MI355X" in out.stderr and "but WORLD_SIZE" not in out.stderr
