@@ -512,3 +512,28 @@ def test_head_backward_kernel(R, W, C):
     assert torch.allclose(g2, ref_g2, rtol=1e-5, atol=1e-5)
     assert torch.allclose(db2, ref_g2.double().sum(0).float(), rtol=1e-4, atol=1e-2)
     assert torch.allclose(dw3, (g3.double().t() @ h2.double()).float(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("R,C", [(10007, 256), (300, 128), (4097, 64)])
+def test_linear_mask_backward_kernel(R, C):
+    """HipLinearMaskBackwardBx3_<C>: g_out = [h > 0] * (g_in . W) with the product in bf16x3 arithmetic -- against the
+    float64 product: float32-accurate (relative error of the size of a float32 GEMM's own), mask exact, ragged R"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training.update_kernels import UpdateKernels
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    k = UpdateKernels(fm)
+    torch.manual_seed(R + C)
+    g = torch.randn(R, C, device="cuda")
+    w = torch.randn(C, C, device="cuda") / C ** 0.5
+    h = torch.relu(torch.randn(R, C, device="cuda"))
+    assert k.supports_linear_mask_backward(g, w, h)
+    got = k.linear_mask_backward(g, w, h)
+    exact = (g.double() @ w.double()) * (h > 0)
+    f32 = (g @ w) * (h > 0)  # the framework's float32 GEMM, for scale
+    err, err_f32 = float((got.double() - exact).abs().max()), float((f32.double() - exact).abs().max())
+    assert err <= max(4.0 * err_f32, 2e-6), (err, err_f32)
+    assert torch.equal(got == 0, exact == 0) or float(((got == 0) != (exact == 0)).float().mean()) < 1e-6

@@ -409,9 +409,9 @@ __device__ __forceinline__ void mlp_fetch_kb(float *buf, const float *src, int p
 // operand reads of the next pair are issued before the MFMAs of the current one.  `sync` runs after the first pair.
 // `fill` runs inside the scheduling region of the first pair's MFMAs: independent VALU / store work (the NEXT k-tile's
 // activation split) that the matrix pipe's 32-cycle issue gaps absorb.
-template <int TN, typename Sync, typename Fill>
+template <int TN, typename Sync, typename Fill, typename Late>
 __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *buf, const mlp_bf8 (&b)[3][2], int lane,
-                                              Sync sync, Fill fill) {
+                                              Sync sync, Fill fill, Late late) {
   constexpr int G = TN < 2 ? 1 : 2, NG = TN / G;
   const mlp_bf8 *const w = (const mlp_bf8 *)buf;  // [term][tn][k half][lane]
   mlp_bf8 a[2][G][3][2];
@@ -437,9 +437,18 @@ __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *b
 #pragma unroll
         for (int t = 0; t < G; ++t)
           acc[gi * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][t][WT[m]][q], b[XT[m]][q], acc[gi * G + t], 0, 0, 0);
-    if (gi == 0) sync();
+    if (gi == 0) {
+      sync();
+      late();  // (global loads issued here have a whole chunk until the next hand-over's vmcnt(0))
+    }
   }
 #undef MLP3_READ
+}
+
+template <int TN, typename Sync, typename Fill>
+__device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *buf, const mlp_bf8 (&b)[3][2], int lane,
+                                              Sync sync, Fill fill) {
+  mlp_chunk_bx3<TN>(acc, buf, b, lane, sync, fill, [] {});
 }
 
 // one layer's post-ReLU activations of this wavefront's 32 agents -> row-major [row][H]: register s of tile tn holds
@@ -579,6 +588,89 @@ __device__ __forceinline__ void mlp_impl_bx3(const MlpArgs &p, float *lds) {
     if (p.h2_out) mlp_store_activations<TN2>(p.h2_out + ((long)t_row * p.n_rows + g) * (32 * TN2), acc2, valid, h);
   }
   mlp_epilogue<TN3>(p, lds, acc3, g, valid, src_row, wave, lane, j, h);
+}
+
+// ---- one hidden layer's INPUT gradient with the ReLU mask of the layer under it, bf16x3:  g_out = [h > 0] * (g_in . W)
+// for g_in [R][C] (the gradient with respect to this layer's pre-activations, already masked), W [C out][C in] and h [R][C]
+// (the post-ReLU activations of the layer under it).  The update's framework path is a square GEMM (hipBLASLt, ~90 % of the
+// f32 matrix peak: 9.3 ms at configs[2]) that writes the unmasked gradient, and a mask pass that reads it back with h and
+// writes it again (6 ms): here the product runs on the bf16 matrix cores at float32 accuracy (the forward's arithmetic,
+// 2.7 x the f32 matrix rate) and the mask is applied to the accumulators, so 30 GB move once instead of 50.
+// Transposed like the forward: G_out^T = W^T . G_in^T, a wavefront owns 32 rows (tile columns); A operand = W^T packed
+// with the first-layer mapping over the contraction index (training/update_kernels.py), streamed through the same three
+// LDS buffers; B operand = this wavefront's rows of g_in, loaded one k-tile ahead and split in the MFMAs' shadow.
+template <int TN>
+__device__ __forceinline__ void mlp_mask_backward_bx3(const float *__restrict__ g_in, const float *__restrict__ wpk,
+                                                      const float *__restrict__ h_mask, float *__restrict__ g_out,
+                                                      long R, float *lds) {
+  constexpr int C = 32 * TN, CHUNK = TN * 1536, NC = TN;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const long row = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 32 + j;
+  const bool valid = row < R;
+  const float *const grow = g_in + (valid ? row : R - 1) * C;
+  int c = 0;
+  auto buffer = [&](int cc) -> float * { return lds + (cc % 3) * CHUNK; };
+  auto chunk_src = [&](int cc) -> const float * { return wpk + (size_t)cc * TN * 1536; };
+  mlp_fetch_kb(buffer(0), chunk_src(0), 6 * TN, wave, lane);
+  // k-tile kt of this lane's row: contraction indices [32 kt + 16 q + 8 h, + 8), q = 0, 1
+  mlp_v16 raw[2];
+  auto load_slice = [&](int kt, mlp_v16 &dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e4 = 0; e4 < 2; ++e4) {
+        const mlp_v4 v = *(const mlp_v4 *)(grow + 32 * kt + 16 * q + 8 * h + 4 * e4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[8 * q + 4 * e4 + e] = v[e];
+      }
+  };
+  load_slice(0, raw[0]);
+  if (NC > 1) load_slice(1, raw[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // chunk 0 is published
+  if (NC > 1) mlp_fetch_kb(buffer(1), chunk_src(1), 6 * TN, wave, lane);
+  auto sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 2 < NC) mlp_fetch_kb(buffer(c + 2), chunk_src(c + 2), 6 * TN, wave, lane);
+  };
+  mlp_bf8 xs[2][3][2];
+  mlp_split3(raw[0], xs[0]);
+  mlp_v16 acc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[tn][s] = 0.0f;
+  mlp_v4 hm[TN][4];  // the mask layer's activations of this lane's 4-unit runs (loaded behind the last hand-over)
+#pragma unroll
+  for (int kt = 0; kt < TN; ++kt) {
+    mlp_chunk_bx3<TN>(
+        acc, buffer(c), xs[kt & 1], lane, sync,
+        [&] { if (kt + 1 < TN) mlp_split3(raw[(kt + 1) & 1], xs[(kt + 1) & 1]); },   // (loaded a chunk ago)
+        [&] {
+          if (kt + 2 < TN) load_slice(kt + 2, raw[kt & 1]);  // (raw[kt & 1] was split during the previous chunk)
+          if (kt == TN - 1) {
+            const float *const hrow = h_mask + (valid ? row : R - 1) * C;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) hm[tn][q] = *(const mlp_v4 *)(hrow + 32 * tn + 8 * q + 4 * h);
+          }
+        });
+    ++c;
+  }
+  if (valid) {
+    float *const orow = g_out + row * C;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mlp_v4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hm[tn][q][e] > 0.0f ? acc[tn][4 * q + e] : 0.0f;
+        *(mlp_v4 *)(orow + 32 * tn + 8 * q + 4 * h) = v;
+      }
+  }
 }
 
 }  // namespace
@@ -721,6 +813,16 @@ extern "C" {
     WD_MLP_ACT_PACK();                                                                                \
     mlp_impl_bx3<H1 / 32, H2 / 32, KT1>(p, (float *)mlp_smem);                                        \
   }
+// HipLinearMaskBackwardBx3_<C>: g_out = [h > 0] * (g_in . W), C x C layer; 256 threads, dynamic LDS = 3 * C / 32 * 6144 bytes
+#define WD_MLP_MASK_BACKWARD(CC)                                                                                      \
+  __global__ void __launch_bounds__(256, 1) HipLinearMaskBackwardBx3_##CC(const float *g_in, const float *wpk,        \
+                                                                          const float *h_mask, float *g_out, long R) { \
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                                          \
+    mlp_mask_backward_bx3<CC / 32>(g_in, wpk, h_mask, g_out, R, (float *)mlp_smem);                                   \
+  }
+WD_MLP_MASK_BACKWARD(256)
+WD_MLP_MASK_BACKWARD(128)
+WD_MLP_MASK_BACKWARD(64)
 WD_MLP_KERNEL(256, 256, 1)
 WD_MLP_KERNEL(256, 256, 2)
 WD_MLP_KERNEL(256, 256, 3)

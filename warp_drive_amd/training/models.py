@@ -85,6 +85,9 @@ class FullyConnected(nn.Module):
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
         fused_tail = not torch.is_autocast_enabled(obs.device.type) and obs.dtype == torch.float32
+        if fused_tail and len(self.fc) == 2 and not obs.requires_grad:  # the usual network: one node, one planned backward
+            l1, l2 = self.fc["0"][0], self.fc["1"][0]
+            return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, None, None, None)
         for i in range(len(self.fc) - (1 if fused_tail else 0)):
             lin = self.fc[str(i)][0]
             x = _Affine.apply(x, lin.weight, lin.bias, True)
@@ -99,10 +102,9 @@ class FullyConnected(nn.Module):
         a read and only the backward runs (training/policy_kernel.py::FusedRolloutTick `stored`).  Two hidden layers."""
         assert len(self.fc) == 2
         l1, l2 = self.fc["0"][0], self.fc["1"][0]
-        x = _AffineStored.apply(obs, l1.weight, l1.bias, True, h1)
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        return _TailHead.apply(x, l2.weight, l2.bias, w, b, h2, out)
+        return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, h1, h2, out)
 
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
@@ -229,6 +231,51 @@ class _TailHead(torch.autograd.Function):
         gw2 = _weight_grad(g2, h1_2d)
         gh1 = (g2 @ w2).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
         return gh1, gw2, gb2, gw3, gb3, None, None
+
+
+class _MlpTwoHidden(torch.autograd.Function):
+    """A network of two hidden ReLU layers and the output layer as ONE autograd node (float32), so that its backward is
+    the sequence this trainer wants rather than what per-layer nodes compose to:
+        g3 -> HipHeadBackward (g2 masked, bias gradient of layer 2, weight gradient of the output layer: one pass over h2)
+           -> weight gradient of layer 2 (GEMM)
+           -> HipLinearMaskBackwardBx3 (g1 = [h1 > 0] * (g2 . W2): the square product on the bf16 matrix cores at float32
+              accuracy with the mask applied to its accumulators -- a GEMM and a mask pass before)
+           -> bias and weight gradient of layer 1
+    each step falling back to the framework's operations where a kernel does not cover the shape.  `stored` = (h1, h2, out)
+    already known from the rollout (nothing is computed going forward) or None."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, h1_stored, h2_stored, out_stored):
+        x2 = x.reshape(-1, x.shape[-1])
+        if h1_stored is None:
+            h1 = _linear_relu(x2, w1, b1)
+            h2 = _linear_relu(h1, w2, b2)
+            out = torch.addmm(b3, h2, w3.t())
+        else:
+            h1, h2 = h1_stored.reshape(-1, w1.shape[0]), h2_stored.reshape(-1, w2.shape[0])
+            out = out_stored.reshape(-1, w3.shape[0])
+        ctx.save_for_backward(x2, w2, w3, h1, h2)
+        return out.view(*x.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w2, w3, h1, h2 = ctx.saved_tensors
+        g3 = g.reshape(-1, g.shape[-1])
+        kernels = update_kernels.active()
+        if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
+            g2, gb2, gw3 = kernels.head_backward(g3, w3, h2)
+        else:
+            g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
+            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
+        gb3 = _column_sums(g3)
+        gw2 = _weight_grad(g2, h1)
+        if kernels is not None and kernels.supports_linear_mask_backward(g2, w2, h1):
+            g1 = kernels.linear_mask_backward(g2, w2, h1)
+        else:
+            g1 = torch.ops.aten.threshold_backward(g2 @ w2, h1, 0)
+        gb1 = _column_sums(g1)
+        gw1 = _weight_grad(g1, x2)
+        return None, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None
 
 
 class _AffineStored(torch.autograd.Function):

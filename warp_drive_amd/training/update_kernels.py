@@ -101,6 +101,36 @@ class UpdateKernels:
         return g2, db2.sum(dim=0), dw3.sum(dim=0)
 
 
+    # ------------------------------------------------ a hidden layer's input gradient + the mask of the layer under it
+    def supports_linear_mask_backward(self, g_in, w, h):
+        C = w.shape[0]
+        return (g_in.is_cuda and g_in.dtype == w.dtype == h.dtype == torch.float32 and w.shape == (C, C)
+                and C in (64, 128, 256) and g_in.shape == h.shape and g_in.shape[-1] == C and g_in.is_contiguous()
+                and h.is_contiguous())
+
+    def linear_mask_backward(self, g_in, w, h):
+        """g_in [R, C] (gradient with respect to a C x C layer's pre-activations), w [C out, C in], h [R, C] = the post-ReLU
+        activations of the layer under it -> (g_in @ w) * [h > 0], the product in bf16x3 arithmetic (float32-accurate: six
+        bf16 partial products per float32 product, as the rollout's forward kernel)"""
+        from warp_drive_amd.training.policy_kernel import _pack_indices_bx3, split_bf16x3
+
+        R, C = h.shape
+        tn = C // 32
+        key = ("mask_backward", C, str(h.device))
+        if key not in self._head_backward_fns:
+            name = f"HipLinearMaskBackwardBx3_{C}"
+            self._fm.initialize_functions([name])
+            rows, cols = _pack_indices_bx3(tn, tn, True)
+            self._head_backward_fns[key] = (self._fm.get_function(name), torch.from_numpy(rows).to(h.device),
+                                            torch.from_numpy(cols).to(h.device))
+        fn, rows, cols = self._head_backward_fns[key]
+        # A operand of G_out^T = W^T . G_in^T: rows = this layer's INPUT units, contraction over its output units
+        wpk = split_bf16x3(w.detach().t().contiguous())[:, rows, cols].transpose(0, 1).contiguous()
+        g_out = torch.empty_like(h)
+        fn(g_in, wpk, h, g_out, np.int64(R), block=(256, 1, 1), grid=((R + 127) // 128, 1), shared=3 * tn * 6144)
+        return g_out
+
+
 class FusedObjective(torch.autograd.Function):
     """loss = policy_loss + vf_coeff * vf_loss - ent_coeff * mean_entropy as ONE kernel that also produces d loss / d
     out; `terms` (float64 [3], detached: policy loss, value loss, mean entropy) is returned beside it for the metrics."""
