@@ -1,0 +1,22 @@
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch, time
+from warp_drive_amd.managers.function_manager import HIPFunctionManager
+from warp_drive_amd.training.update_kernels import UpdateKernels
+from warp_drive_amd.training import models
+fm = HIPFunctionManager(num_agents=1, num_envs=1); fm.load_hip_from_binary_file()
+k = UpdateKernels(fm)
+R = 10_000_000
+g = torch.randn(R, 256, device="cuda"); h = torch.randn(R, 256, device="cuda"); x = torch.randn(R, 71, device="cuda")
+def t(f, n=5):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print("dW2 kernel %.2f ms" % t(lambda: k.weight_grad(g, h)))
+print("dW1+db1 kernel %.2f ms" % t(lambda: k.weight_grad(g, x, with_bias=True)))
+if len(sys.argv) > 1:
+    sys.exit(0)
+def bmm(a, b):
+    return torch.bmm(a.reshape(250, R // 250, a.shape[1]).transpose(1, 2), b.reshape(250, R // 250, b.shape[1])).sum(0)
+print("dW2 bmm %.2f ms" % t(lambda: bmm(g, h)))
+print("dW1 bmm %.2f ms + colsum %.2f ms" % (t(lambda: bmm(g, x)), t(lambda: models._column_sums(g))))

@@ -537,3 +537,37 @@ def test_linear_mask_backward_kernel(R, C):
     err, err_f32 = float((got.double() - exact).abs().max()), float((f32.double() - exact).abs().max())
     assert err <= max(4.0 * err_f32, 2e-6), (err, err_f32)
     assert torch.equal(got == 0, exact == 0) or float(((got == 0) != (exact == 0)).float().mean()) < 1e-6
+
+
+@pytest.mark.parametrize("R,ci,bias", [(70001, 256, False), (65536 + 4, 71, True), (1 << 20, 71, True), (300004, 33, False),
+                                       (1 << 20, 256, False)])
+def test_weight_grad_kernel(R, ci, bias, monkeypatch):
+    """HipWeightGradBx3_256x{256,96}: g^T @ x over the batch in bf16x3 arithmetic (+ the bias gradient as a column of ones)
+    -- against the float64 product: float32-accurate (error of the size of the framework's float32 GEMM's own), ragged
+    row counts (a last step of fewer than 16 rows, blocks with nothing to do), narrow inputs padded with zero columns"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training.update_kernels import UpdateKernels
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    k = UpdateKernels(fm)
+    torch.manual_seed(R + ci)
+    g = torch.randn(R, 256, device="cuda") * (torch.rand(R, 1, device="cuda") < 0.7)   # (whole zero rows, as masked gradients have)
+    x = torch.relu(torch.randn(R, ci, device="cuda")) + 0.25
+    assert k.supports_weight_grad(g, x, with_bias=bias)
+    gw, gb = k.weight_grad(g, x, with_bias=bias)
+    exact = g.double().t() @ x.double()
+    f32 = g.t() @ x
+    err, err_f32 = float((gw.double() - exact).abs().max()), float((f32.double() - exact).abs().max())
+    scale = float(exact.abs().max())
+    assert gw.shape == (256, ci) and err <= max(4.0 * err_f32, 2e-6 * scale), (err, err_f32, scale)
+    if bias:
+        exact_b = g.double().sum(0)
+        assert float((gb.double() - exact_b).abs().max()) <= 2e-5 * float(exact_b.abs().max()) + 1e-3
+    else:
+        assert gb is None
+    # rows below the threshold and other widths stay with the framework
+    assert not k.supports_weight_grad(g[:1000], x[:1000])
+    assert not k.supports_weight_grad(g[:, :128].contiguous(), x)

@@ -144,8 +144,13 @@ def _column_sums(g):
 def _weight_grad(g, x):
     """g^T @ x for [rows, out] x [rows, in] with ~1e7 rows: one GEMM whose contraction is 1e7 long and
     whose result is 256 x 256 leaves most of the chip idle (5-10 ms at 1 TB/s on MI355X); as a batch of
-    S independent slices of the rows followed by a sum over S it streams both operands at memory speed."""
+    S independent slices of the rows followed by a sum over S it streams both operands at memory speed.
+    float32 operands of the shapes HipWeightGradBx3_* covers go there instead (training/update_kernels.py::weight_grad:
+    the batched GEMM already runs at the f32 matrix peak; bf16x3 arithmetic is what is left)."""
     rows = g.shape[0]
+    kernels = update_kernels.active()
+    if kernels is not None and kernels.supports_weight_grad(g, x):
+        return kernels.weight_grad(g, x)[0]
     if rows >= (1 << 20):
         for sl in (250, 256, 200, 128, 125, 100, 64, 50, 32):
             if rows % sl == 0:
@@ -273,8 +278,10 @@ class _MlpTwoHidden(torch.autograd.Function):
             g1 = kernels.linear_mask_backward(g2, w2, h1)
         else:
             g1 = torch.ops.aten.threshold_backward(g2 @ w2, h1, 0)
-        gb1 = _column_sums(g1)
-        gw1 = _weight_grad(g1, x2)
+        if kernels is not None and kernels.supports_weight_grad(g1, x2, with_bias=True):
+            gw1, gb1 = kernels.weight_grad(g1, x2, with_bias=True)  # (the bias gradient rides as a column of ones)
+        else:
+            gb1, gw1 = _column_sums(g1), _weight_grad(g1, x2)
         return None, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None
 
 

@@ -130,6 +130,43 @@ class UpdateKernels:
         fn(g_in, wpk, h, g_out, np.int64(R), block=(256, 1, 1), grid=((R + 127) // 128, 1), shared=3 * tn * 6144)
         return g_out
 
+    # ------------------------------------------------------------------ a layer's weight (and bias) gradient over the batch
+    WEIGHT_GRAD_MIN_ROWS = 1 << 16   # below this the framework GEMM is as good (launch-bound either way)
+    WEIGHT_GRAD_STAGES = 4           # WD_WEIGHT_GRAD_STAGES of the kernel source
+
+    @staticmethod
+    def supports_weight_grad(g, x, with_bias=False):
+        ci = x.shape[-1]
+        return (g.is_cuda and g.dtype == x.dtype == torch.float32 and g.dim() == x.dim() == 2 and g.shape[0] == x.shape[0]
+                and g.shape[0] >= UpdateKernels.WEIGHT_GRAD_MIN_ROWS and g.shape[1] == 256 and g.is_contiguous()
+                and x.is_contiguous() and (ci < 96 or (ci == 256 and not with_bias)))
+
+    def weight_grad(self, g, x, with_bias=False):
+        """g [R, 256] (gradient with respect to a layer's pre-activations), x [R, ci] (the layer's input), ci = 256 or < 96 ->
+        (g^T @ x [256, ci], column sums of g [256] or None) in bf16x3 arithmetic (HipWeightGradBx3_*: six bf16 partial products
+        per float32 product, float32 accumulation); with_bias: the bias gradient rides as one more input column of ones"""
+        R, ci = x.shape
+        cip = 256 if ci == 256 else 96
+        key = ("weight_grad", cip, str(g.device))
+        if key not in self._head_backward_fns:
+            name = f"HipWeightGradBx3_256x{cip}"
+            self._fm.initialize_functions([name])
+            cus = torch.cuda.get_device_properties(g.device).multi_processor_count
+            self._head_backward_fns[key] = (self._fm.get_function(name), int(cus))
+        fn, blocks = self._head_backward_fns[key]
+        main = R - R % 32   # the kernel takes pairs of whole 16-row steps; the last R % 32 rows are added below
+        rows_per_block = -(-main // (32 * blocks)) * 32
+        blocks = -(-main // rows_per_block)
+        partial = torch.empty((blocks, 256, cip), dtype=torch.float32, device=g.device)
+        fn(g, x, partial, np.int64(main), np.int32(ci), np.int32(ci if with_bias else -1), np.int64(rows_per_block),
+           block=(256, 1, 1), grid=(blocks, 1), shared=self.WEIGHT_GRAD_STAGES * 4 * (16 * 260 + (16 * 260 if cip == 256 else 2048)))
+        total = partial.sum(dim=0)
+        gw, gb = total[:, :ci], (total[:, ci] if with_bias else None)
+        if main < R:
+            gw = gw + g[main:].t() @ x[main:]
+            gb = gb + g[main:].sum(dim=0) if with_bias else None
+        return gw, gb
+
 
 class FusedObjective(torch.autograd.Function):
     """loss = policy_loss + vf_coeff * vf_loss - ent_coeff * mean_entropy as ONE kernel that also produces d loss / d
