@@ -33,5 +33,5 @@ timeout 200 python scripts/cartpole_rollout_timing.py 2>&1 | grep -v "amdgpu.ids
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/up; timeout 200 rocprofv3 --kernel-trace -d /tmp/up -o up -- python $R/scripts/update_profile.py float32 > /dev/null 2>&1
 cd $R; db=$(find /tmp/up -name "*.db" | head -1)
-[ -n "$db" ] && (echo "# rocprofv3 --kernel-trace -- python scripts/update_profile.py float32   (one rollout of 50 ticks + 3 updates at configs[2])"; python scripts/rocpd_summary.py kernel $db | head -40) > $O/${TAG}_update_kernels.txt
+[ -n "$db" ] && (echo "# rocprofv3 --kernel-trace -- python scripts/update_profile.py float32   (3 x (rollout of 50 ticks + update) at configs[2])"; python scripts/rocpd_summary.py kernel $db | head -40) > $O/${TAG}_update_kernels.txt
 ls $O | wc -l

@@ -6,8 +6,8 @@ from warp_drive_amd.training.scripts.train import setup_trainer
 dt = sys.argv[1] if len(sys.argv) > 1 else "bfloat16"
 tr = setup_trainer("tag_continuous", {"trainer": {"num_envs": 2000, "train_batch_size": 100000, "update_dtype": dt}},
                    results_dir="/tmp/up", verbose=False)
-tr._generate_rollout_batch()
-for it in range(3):
+for it in range(3):   # (a rollout before every update, as in training: the update reads the activations it stored)
+    tr._generate_rollout_batch()
     tr._update_model_params(it, False)
 torch.cuda.synchronize()
 tr.graceful_close()

@@ -14,6 +14,9 @@ def t(f, n=5):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 print("dW2 kernel %.2f ms" % t(lambda: k.weight_grad(g, h)))
 print("dW1+db1 kernel %.2f ms" % t(lambda: k.weight_grad(g, x, with_bias=True)))
+w2 = torch.randn(256, 256, device="cuda") / 16
+hh = torch.relu(h)
+print("mask backward %.2f ms" % t(lambda: k.linear_mask_backward(g, w2, hh)))
 if len(sys.argv) > 1:
     sys.exit(0)
 def bmm(a, b):

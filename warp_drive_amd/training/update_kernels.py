@@ -127,7 +127,11 @@ class UpdateKernels:
         # A operand of G_out^T = W^T . G_in^T: rows = this layer's INPUT units, contraction over its output units
         wpk = split_bf16x3(w.detach().t().contiguous())[:, rows, cols].transpose(0, 1).contiguous()
         g_out = torch.empty_like(h)
-        fn(g_in, wpk, h, g_out, np.int64(R), block=(256, 1, 1), grid=((R + 127) // 128, 1), shared=3 * tn * 6144)
+        # a wavefront = 32 rows; 8 per block where a weight chunk's 6 * tn KB divide over 8 wavefronts (C = 128, 256): the
+        # chunk fetched into LDS then serves twice the rows (9.75 -> 9.2 ms at configs[2])
+        waves = 8 if (6 * tn) % 8 == 0 else 4
+        fn(g_in, wpk, h, g_out, np.int64(R), block=(64 * waves, 1, 1), grid=((R + 32 * waves - 1) // (32 * waves), 1),
+           shared=3 * tn * 6144)
         return g_out
 
     # ------------------------------------------------------------------ a layer's weight (and bias) gradient over the batch
