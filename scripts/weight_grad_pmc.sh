@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the weight-gradient kernels (separate rocprofv3 passes); workload = scripts/weight_grad_timing.py.
+# SQ counters of the update's bf16x3 kernels (weight gradients, input gradient) (separate rocprofv3 passes); workload = scripts/weight_grad_timing.py.
 # Run on the GPU box:  bash scripts/weight_grad_pmc.sh > gpurun_out/weight_grad_pmc.txt
 cd "$(dirname "$0")/.."
 R=$PWD
@@ -16,6 +16,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
     python $R/scripts/rocpd_summary.py pmc $db $c | python -c "
 import json,sys
 for r in json.load(sys.stdin):
-    if 'WeightGrad' in r['kernel']: print('%-28s %-28s avg=%.4g' % (r['counter'], r['kernel'], r['avg']))"
+    if 'Bx3' in r['kernel']: print('%-28s %-28s avg=%.4g' % (r['counter'], r['kernel'], r['avg']))"
   done
 done

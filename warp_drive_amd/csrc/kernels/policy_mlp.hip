@@ -445,7 +445,7 @@ __device__ __forceinline__ void mlp_chunk_bx3(mlp_v16 (&acc)[TN], const float *b
       for (int m = 0; m < 6; ++m)
 #pragma unroll
         for (int t = 0; t < G; ++t)
-          acc[gi * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][t][WT[m]][q], b[XT[m]][q], acc[gi * G + t], 0, 0, 0);
+                    acc[gi * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][t][WT[m]][q], b[XT[m]][q], acc[gi * G + t], 0, 0, 0);
     if (gi == 0) {
       sync();
       late();  // (global loads issued here have a whole chunk until the next hand-over's vmcnt(0))
@@ -660,9 +660,41 @@ __device__ __forceinline__ void mlp_mask_backward_bx3(const float *__restrict__ 
         });
     ++c;
   }
-  // the mask layer's activations of this lane's 4-unit runs are loaded here, a tile at a time (holding all of them across
-  // the last chunk cost 128 registers: one wavefront per SIMD; the block's other wavefronts cover the latency instead)
-  if (valid) {
+  // Epilogue.  An accumulator lane holds 4-unit runs of ONE row: stored as they are, an instruction writes 32-byte pieces
+  // of 32 rows (and reads the mask layer's activations the same way) and the block ends on the memory pipe's issue rate,
+  // not on bandwidth.  Where a dead weight buffer leaves room (4.5 KB per wavefront), each 32 x 32 tile goes through LDS
+  // and comes back row-major: lane l takes 16 bytes of row l / 8, so an instruction covers whole 128-byte lines of 8 rows.
+  constexpr bool STAGED = TN == 8 || TN == 4;
+  if constexpr (STAGED) {
+    // after the last chunk's barrier nobody reads the buffers of chunks NC - 2 and NC - 3: buffer 0 (TN = 8) / 1 and 2 (TN = 4)
+    float *const tile = lds + (TN == 8 ? 0 : CHUNK) + wave * 1152;  // 32 rows x 36 floats
+    const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
+    const int r8 = lane >> 3, cseg = 4 * (lane & 7);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const mlp_v4 v = {acc[tn][4 * q], acc[tn][4 * q + 1], acc[tn][4 * q + 2], acc[tn][4 * q + 3]};
+        *(mlp_v4 *)(tile + j * 36 + 8 * q + 4 * h) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a wavefront's LDS operations execute in order)
+      mlp_v4 hm[4], gv[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const long r = row0 + 8 * it + r8;
+        hm[it] = *(const mlp_v4 *)(h_mask + (r < R ? r : R - 1) * C + 32 * tn + cseg);
+        gv[it] = *(const mlp_v4 *)(tile + (8 * it + r8) * 36 + cseg);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const long r = row0 + 8 * it + r8;
+        mlp_v4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hm[it][e] > 0.0f ? gv[it][e] : 0.0f;
+        if (r < R) *(mlp_v4 *)(g_out + r * C + 32 * tn + cseg) = v;
+      }
+    }
+  } else if (valid) {
     const float *const hrow = h_mask + row * C;
     float *const orow = g_out + row * C;
 #pragma unroll
