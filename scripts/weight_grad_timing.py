@@ -17,6 +17,8 @@ print("dW1+db1 kernel %.2f ms" % t(lambda: k.weight_grad(g, x, with_bias=True)))
 w2 = torch.randn(256, 256, device="cuda") / 16
 hh = torch.relu(h)
 print("mask backward %.2f ms" % t(lambda: k.linear_mask_backward(g, w2, hh)))
+g3 = torch.randn(R, 43, device="cuda"); w3 = torch.randn(43, 256, device="cuda") * 0.2
+print("head backward %.2f ms" % t(lambda: k.head_backward(g3, w3, hh)))
 if len(sys.argv) > 1:
     sys.exit(0)
 def bmm(a, b):

@@ -489,10 +489,11 @@ def test_update_from_stored_rollout_activations(tmp_path):
         tr.graceful_close()
 
 
-@pytest.mark.parametrize("R,W,C", [(10007, 43, 256), (5000, 6, 64), (777, 3, 128)])
+@pytest.mark.parametrize("R,W,C", [(10007, 43, 256), (5000, 6, 64), (777, 3, 128), (200007, 43, 256), (70000, 6, 256), (65536 + 31, 3, 256)])
 def test_head_backward_kernel(R, W, C):
-    """HipHeadBackward_W<w>: the output layer's backward, the hidden layer's ReLU mask + bias gradient and the output
-    layer's weight gradient in one pass, against the three framework operations it replaces"""
+    """HipHeadBackward_W<w> (vector units) and, for 256 hidden units and >= 65536 rows, HipHeadBackwardBx3_W<w> (bf16 matrix
+    cores, bf16x3): the output layer's backward, the hidden layer's ReLU mask + bias gradient and the output layer's weight
+    gradient in one pass, against the three framework operations it replaces (ragged row counts: the last R % 32 rows)"""
     from tests.hip_harness import require_gpu
     from warp_drive_amd.managers.function_manager import HIPFunctionManager
     from warp_drive_amd.training.update_kernels import UpdateKernels

@@ -88,6 +88,8 @@ class UpdateKernels:
         (g2 [R, C] = (g3 @ w3) * [h2 > 0], db2 [C] = its column sums, dw3 [W, C] = g3^T @ h2) in one pass"""
         R, C = h2.shape
         W = w3.shape[0]
+        if C == 256 and R >= self.WEIGHT_GRAD_MIN_ROWS:
+            return self._head_backward_bx3(g3.contiguous(), w3, h2)
         fn = self._head_backward_fns.get(W)
         if fn is None:
             self._fm.initialize_functions([f"HipHeadBackward_W{W}"])
@@ -100,6 +102,47 @@ class UpdateKernels:
         fn(g3, w3, h2, g2, db2, dw3, np.int64(R), np.int32(self.ROWS_PER_BLOCK), block=(C, 1, 1), grid=(blocks, 1), shared=0)
         return g2, db2.sum(dim=0), dw3.sum(dim=0)
 
+
+    HEAD_BACKWARD_STAGES = 3   # WD_HEAD_BACKWARD_STAGES of the kernel source
+
+    def _head_backward_bx3(self, g3, w3, h2):
+        """`head_backward` for 256 hidden units on the bf16 matrix cores (HipHeadBackwardBx3_W<W>: bf16x3 arithmetic,
+        float32-accurate); the last R % 32 rows go through the framework"""
+        from warp_drive_amd.training.policy_kernel import split_bf16x3
+
+        R, C = h2.shape
+        W = w3.shape[0]
+        ks = (W + 15) // 16
+        key = ("head_backward_bx3", W, str(h2.device))
+        if key not in self._head_backward_fns:
+            name = f"HipHeadBackwardBx3_W{W}"
+            self._fm.initialize_functions([name])
+            cus = torch.cuda.get_device_properties(h2.device).multi_processor_count
+            self._head_backward_fns[key] = (self._fm.get_function(name), int(cus))
+        fn, blocks = self._head_backward_fns[key]
+        # W3^T as the kernel's A operand, in register-image order [wave][tile][k step][term][lane = 32 kg + i][e]:
+        # element = W3[k = 16 ks + 8 kg + e][unit = 64 wave + 32 tile + i], zero for k >= W
+        wt = torch.zeros((C, 16 * ks), dtype=torch.float32, device=h2.device)
+        wt[:, :W] = w3.detach().t()
+        w3pk = (split_bf16x3(wt).reshape(3, 4, 2, 32, ks, 2, 8)     # [term][wave][tile][i][k step][kg][e]
+                .permute(1, 2, 4, 0, 5, 3, 6).contiguous())          # [wave][tile][k step][term][kg][i][e]
+        main = R - R % 32
+        rows_per_block = -(-main // (32 * blocks)) * 32
+        blocks = -(-main // rows_per_block)
+        g2 = torch.empty_like(h2)
+        db2 = torch.empty((blocks, C), dtype=torch.float32, device=h2.device)
+        dw3 = torch.empty((blocks, W, C), dtype=torch.float32, device=h2.device)
+        g3_max = 31 * W + max(32 * ((W + 31) // 32), 16 * ks) - 1
+        g3_floats = 1024 * ((g3_max // 256 + 1 + 3) // 4)
+        fn(g3, w3pk, h2, g2, db2, dw3, np.int64(main), np.int64(rows_per_block), block=(256, 1, 1), grid=(blocks, 1),
+           shared=self.HEAD_BACKWARD_STAGES * 4 * (g3_floats + 32 * 260))
+        db2, dw3 = db2.sum(dim=0), dw3.sum(dim=0)
+        if main < R:
+            tail = torch.ops.aten.threshold_backward(g3[main:] @ w3, h2[main:], 0)
+            g2[main:] = tail
+            db2 = db2 + tail.sum(dim=0)
+            dw3 = dw3 + g3[main:].t() @ h2[main:]
+        return g2, db2, dw3
 
     # ------------------------------------------------ a hidden layer's input gradient + the mask of the layer under it
     def supports_linear_mask_backward(self, g_in, w, h):
