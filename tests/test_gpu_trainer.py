@@ -572,3 +572,28 @@ def test_weight_grad_kernel(R, ci, bias, monkeypatch):
     # rows below the threshold and other widths stay with the framework
     assert not k.supports_weight_grad(g[:1000], x[:1000])
     assert not k.supports_weight_grad(g[:, :128].contiguous(), x)
+
+
+@pytest.mark.parametrize("T,E,n,W", [(50, 200, 100, 43), (7, 61, 9, 6), (1, 3, 5, 3)])
+def test_discounted_returns_kernel_is_bit_identical(T, E, n, W):
+    """HipDiscountedReturns against losses.discounted_returns (the reference's recursion, a2c.py:80-95): same float32
+    operations in the same order -- returns and advantages bit for bit, done flags of 0 / 1 / 2"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training.losses import discounted_returns
+    from warp_drive_amd.training.update_kernels import UpdateKernels
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    k = UpdateKernels(fm)
+    torch.manual_seed(T + E)
+    out = torch.randn(T, E, n, W, device="cuda")
+    rewards = torch.randn(T, E, n, device="cuda") * 3.0
+    done = torch.randint(0, 3, (T, E), device="cuda", dtype=torch.int32) * (torch.rand(T, E, device="cuda") < 0.2).to(torch.int32)
+    assert k.supports_discounted_returns(rewards, done, out)
+    for gamma in (1.0, 0.97):
+        got, adv = k.discounted_returns(rewards, done, out, gamma)
+        want = discounted_returns(rewards, done, out[..., -1], gamma)
+        assert torch.equal(got, want)
+        assert torch.equal(adv, want - out[..., -1])

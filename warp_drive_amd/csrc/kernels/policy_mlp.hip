@@ -1262,6 +1262,31 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
   if (tid == 0) batch_row[e] = t + 1;
 }
 
+// HipDiscountedReturns: the bootstrapped discounted returns of a training batch (reference a2c.py:80-95),
+//     R[T-1] = done[T-1] ? r[T-1] : V[T-1],   R[t] = r[t] + ((1 - done[t]) * gamma) * R[t+1]
+// one thread per (replica, agent) walking its T steps backwards; V = column `v_col` of the network's output rows of width
+// `w`.  Also writes R - V (the advantages, when the objective does not normalise).  The framework form is a Python loop
+// over T with four small kernels per step: launch-bound, 1.3 ms per policy at T = 50 whatever the batch.  Same operations
+// in the same order in float32 (this object is compiled with -ffp-contract=off): bit-identical.
+__global__ void __launch_bounds__(256) HipDiscountedReturns(const float *__restrict__ rewards, const int *__restrict__ done,
+                                                            const float *__restrict__ out, int w, int v_col, float gamma,
+                                                            int T, int E, int n, float *__restrict__ returns,
+                                                            float *__restrict__ advantages) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (replica, agent)
+  if (i >= (long)E * n) return;
+  const int e = (int)(i / n);
+  const long stride = (long)E * n;
+  float R = 0.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    const long at = (long)t * stride + i;
+    const float d = done[(long)t * E + e] > 0 ? 1.0f : 0.0f, r = rewards[at], v = out[at * w + v_col];
+    if (t == T - 1) R = d * r + (1.0f - d) * v;
+    else R = r + ((1.0f - d) * gamma) * R;
+    returns[at] = R;
+    advantages[at] = R - v;
+  }
+}
+
 // HipPolicyGradientHead: everything between the network's output and its gradient in ONE pass over the batch.  The
 // A2C / PPO objective (reference algorithms/policygradient/a2c.py:97-194, ppo.py:150-228) on `out` [R][W] (W = A0 + A1
 // + 1: the logits of the two heads -- A1 = 0: one head -- then the value) is

@@ -177,6 +177,28 @@ class UpdateKernels:
            shared=3 * tn * 6144)
         return g_out
 
+    # ------------------------------------------------------------------ discounted returns of a batch
+    def discounted_returns(self, rewards, done_flags, out, gamma):
+        """rewards [T, E, n] float32, done_flags [T, E], out [T, E, n, W] (the network's output rows: the value is the last
+        column) -> (returns [T, E, n], returns - values) as ONE kernel, bit-identical to losses.discounted_returns"""
+        T, E, n = rewards.shape
+        W = out.shape[-1]
+        if "returns" not in self._head_backward_fns:
+            self._fm.initialize_functions(["HipDiscountedReturns"])
+            self._head_backward_fns["returns"] = self._fm.get_function("HipDiscountedReturns")
+        returns, adv = torch.empty_like(rewards), torch.empty_like(rewards)
+        self._head_backward_fns["returns"](rewards, done_flags, out, np.int32(W), np.int32(W - 1), np.float32(gamma),
+                                           np.int32(T), np.int32(E), np.int32(n), returns, adv,
+                                           block=(256, 1, 1), grid=((E * n + 255) // 256, 1), shared=0)
+        return returns, adv
+
+    @staticmethod
+    def supports_discounted_returns(rewards, done_flags, out):
+        return (rewards.is_cuda and rewards.dtype == out.dtype == torch.float32 and rewards.dim() == 3 and out.dim() == 4
+                and rewards.is_contiguous() and out.is_contiguous() and done_flags.is_contiguous()
+                and done_flags.dtype == torch.int32 and tuple(done_flags.shape) == tuple(rewards.shape[:2])
+                and tuple(out.shape[:3]) == tuple(rewards.shape))
+
     # ------------------------------------------------------------------ a layer's weight (and bias) gradient over the batch
     WEIGHT_GRAD_MIN_ROWS = 1 << 16   # below this the framework GEMM is as good (launch-bound either way)
     WEIGHT_GRAD_STAGES = 4           # WD_WEIGHT_GRAD_STAGES of the kernel source
