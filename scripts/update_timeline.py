@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernels of ONE update in launch order (name, duration) from a rocprofv3 --kernel-trace database of
+"""Kernels of ONE update in launch order (name, duration; gaps in which no kernel ran) from a rocprofv3 --kernel-trace database of
 scripts/update_profile.py: python scripts/update_timeline.py <db> [min_us]"""
 import sqlite3
 import sys
@@ -11,7 +11,11 @@ rows = c.execute("select name, start, end, grid_x, workgroup_x from kernels orde
 idx = [i for i, r in enumerate(rows) if r[0].startswith("HipPolicyGradientHead")]
 start = idx[-2] if len(idx) >= 2 else 0
 t0 = rows[start][1]
+prev_end = None
 for name, s, e, gx, wg in rows[start:]:
     d = (e - s) / 1e3
+    if prev_end is not None and (s - prev_end) / 1e3 >= min_us:
+        print(f"{(prev_end - t0) / 1e6:9.3f} ms  {(s - prev_end) / 1e3:9.1f} us  -- no kernel running --")
+    prev_end = max(prev_end or e, e)
     if d >= min_us:
         print(f"{(s - t0) / 1e6:9.3f} ms  {d:9.1f} us  grid {gx:>9} wg {wg:>4}  {name[:70]}")
