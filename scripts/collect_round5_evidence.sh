@@ -29,9 +29,12 @@ timeout 120 python scripts/episode_profile.py > $O/${TAG}_episode_profile.txt 2>
 timeout 300 python scripts/rollout_timing.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|over_agents" > $O/${TAG}_rollout_timing.txt
 timeout 200 python scripts/gridworld_rollout_timing.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|over_agents" > $O/${TAG}_gridworld_rollout_timing.txt
 timeout 200 python scripts/cartpole_rollout_timing.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|over_agents" > $O/${TAG}_cartpole_rollout_timing.txt
-# 8. kernel view of the trainer (rollout of 50 ticks + 3 updates)
+# 8. kernel view of the trainer (3 x (rollout of 50 ticks + update))
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/up; timeout 200 rocprofv3 --kernel-trace -d /tmp/up -o up -- python $R/scripts/update_profile.py float32 > /dev/null 2>&1
 cd $R; db=$(find /tmp/up -name "*.db" | head -1)
 [ -n "$db" ] && (echo "# rocprofv3 --kernel-trace -- python scripts/update_profile.py float32   (3 x (rollout of 50 ticks + update) at configs[2])"; python scripts/rocpd_summary.py kernel $db | head -40) > $O/${TAG}_update_kernels.txt
+[ -n "$db" ] && (echo "# the kernels of one update in launch order (>= 100 us; gaps without a kernel >= 100 us): python scripts/update_timeline.py <db of the run above> 100"; python scripts/update_timeline.py $db 100) > $O/${TAG}_update_timeline.txt
+# 9. the update's matrix-core kernels alone, against the framework GEMMs they replace (10 M rows of random data)
+timeout 100 python scripts/weight_grad_timing.py 2>&1 | grep -v "amdgpu.ids" > $O/${TAG}_weight_grad_timing.txt
 ls $O | wc -l
