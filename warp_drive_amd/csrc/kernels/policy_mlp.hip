@@ -1135,7 +1135,9 @@ __device__ __forceinline__ void head_backward_bx3(const float *__restrict__ g3, 
         const int k = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (k < W) dw3_part[((long)blockIdx.x * W + k) * C + 64 * wave + 32 * ut + c] = accw[ot][ut][i];
       }
-  // bias partials: sum over the 32 rows (lanes c) of every (tile, register, h), through LDS
+  // bias partials: sum over the 32 rows (lanes c) of every (tile, register, h), through LDS -- once the LDS-direct loads of
+  // the steps past the slab's end (issued to keep the wait counts uniform) have landed in the stages this reuses
+  wg_wait_loads<0>();
   __syncthreads();
   float *const red = (float *)lds + wave * (2 * 16 * 64);
 #pragma unroll
