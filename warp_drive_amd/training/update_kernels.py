@@ -1,14 +1,26 @@
-"""The update's non-GEMM work as hand-written kernels (csrc/kernels/policy_mlp.hip, the trainer's code object).
+"""The trainer's update as hand-written kernels (csrc/kernels/policy_mlp.hip, the trainer's code object).
 
-At configs[2] a training batch is ~1e7 rows.  The GEMMs of the update are the framework's (hipBLASLt, ~65 % of the
-float32 matrix peak); everything AROUND them used to be framework element-wise / reduction kernels over [rows, 21] and
-[rows, 256] tensors -- as much time as the GEMMs (profiles/r05_update_kernels.txt).  Two kernels replace most of it:
+At configs[2] a training batch is ~1e7 rows.  For a float32 network of two 256-wide hidden layers the whole update runs
+here (training/models.py::_MlpTwoHidden, training/losses.py); other shapes use the kernels that cover them and the
+framework's operations for the rest (profiles/r05_update_kernels.txt, r05_update_timeline.txt):
 
+  discounted_returns     HipDiscountedReturns: bootstrapped returns + advantages of a batch, one thread per (replica, agent)
+                         (reference algorithms/policygradient/a2c.py:80-95; bit-identical to the framework loop over T)
   policy_gradient_head   HipPolicyGradientHead: A2C / PPO objective + its gradient with respect to the network's output
                          in ONE pass (softmax of both heads, log-probability of the taken actions, entropies, value
-                         loss; reference algorithms/policygradient/a2c.py:97-194, ppo.py:150-228)
+                         loss; reference a2c.py:97-194, ppo.py:150-228)
+  head_backward          HipHeadBackwardBx3_W<w> (256 hidden units, bf16 matrix cores) / HipHeadBackward_W<w> (vector units):
+                         the output layer's backward, the last hidden layer's ReLU mask + bias gradient and the output
+                         layer's weight gradient in one pass over the hidden activations
+  linear_mask_backward   HipLinearMaskBackwardBx3_<C>: a hidden layer's input gradient with the ReLU mask of the layer
+                         under it applied to the accumulators
+  weight_grad            HipWeightGradBx3_256x{256,96}: a layer's weight gradient g^T . x over the batch (+ its bias gradient
+                         as a column of ones)
   relu_backward_colsum   HipReluBackwardColumnSums: the ReLU mask of a hidden layer's backward and that layer's bias
-                         gradient in one pass over the [rows, features] gradient
+                         gradient in one pass (the per-layer path of other network shapes)
+
+"Bx3" = bf16x3 arithmetic: every float32 operand is split exactly into three bf16 terms and a product is the float32 sum
+of the six partial products that reach 2^-24 of it -- float32-accurate at 2.7 x the float32 matrix rate.
 
 `install(function_manager)` makes them available to training/models.py and training/losses.py; without it (CPU tests,
 other devices) both modules run their framework paths."""
