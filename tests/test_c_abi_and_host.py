@@ -71,7 +71,7 @@ def test_code_object_has_all_kernels(built):
               "HipTagContinuousStep_K32_N512": "wd_kernels_tc_k32.hsaco",
               "HipTagContinuousTick_K10_N105A21": "wd_kernels_tc_k10_n105a21.hsaco",
               "HipTagContinuousTickA_K10_N105A21": "wd_kernels_tc_k10_n105a21.hsaco",
-              "HipTagGridWorldRollout_N5": "wd_kernels_gw5.hsaco", "HipPolicyMlp_256x256_k3": "wd_kernels_mlp.hsaco",
+              "HipTagGridWorldRollout_N5": "wd_kernels_gw5.hsaco", "HipPolicyMlp_256x256_k3": "wd_kernels_mlp.hsaco", "HipWeightGradBx3_256x256": "wd_kernels_update.hsaco",
               "wd_test_math": "wd_kernels_test.hsaco", "wd_write_probe": "wd_kernels_test.hsaco"}
     for name, obj in wanted.items():
         assert manifest.get(name) == obj, (name, manifest.get(name))
@@ -224,7 +224,8 @@ def test_kernels_do_not_spill_to_scratch(built, tmp_path):
     from warp_drive_amd import build as wd_build
 
     llvm = os.path.join(wd_build.ROCM, "lib", "llvm", "bin")
-    strict = {"wd_kernels.hsaco", "wd_kernels_tc_k10_n105a21.hsaco", "wd_kernels_gw5.hsaco", "wd_kernels_mlp.hsaco"}
+    strict = {"wd_kernels.hsaco", "wd_kernels_tc_k10_n105a21.hsaco", "wd_kernels_gw5.hsaco", "wd_kernels_mlp.hsaco",
+              "wd_kernels_update.hsaco"}
     seen = 0
     for obj in wd_build.UNITS:
         elf = str(tmp_path / (obj + ".elf"))

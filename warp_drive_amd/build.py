@@ -49,7 +49,10 @@ UNITS = {
     # (and its block size: 105 agents = one replica per 128-thread block, envs/tag_continuous.py::_geometry)
     "wd_kernels_tc_k10_n105a21.hsaco": ("tag_continuous.hip", ["-DWD_TC_KM=10", "-DWD_TC_SHAPE_N=105",
                                                                  "-DWD_TC_SHAPE_A=21", "-DWD_TC_SHAPE_THREADS=128"]),
-    "wd_kernels_mlp.hsaco": ("policy_mlp.hip", []),
+    # the trainer's kernels, one source, two objects compiled side by side: the rollout's (policy forward, record) and the
+    # update's (returns, objective, backward passes)
+    "wd_kernels_mlp.hsaco": ("policy_mlp.hip", ["-DWD_MLP_PART=1"]),
+    "wd_kernels_update.hsaco": ("policy_mlp.hip", ["-DWD_MLP_PART=2"]),
     "wd_kernels_gw5.hsaco": ("tag_gridworld_n5.hip", []),
     "wd_kernels_test.hsaco": ("wd_test_kernels.hip", []),
 }

@@ -1203,11 +1203,16 @@ extern "C" {
     weight_grad_bx3<CO_ / 32, CIP_ / 32, WA_, WB_, WD_WEIGHT_GRAD_STAGES>(G, X, partial, R, ci, ones_col,             \
                                                                           rows_per_block, mlp_smem);                  \
   }
+// The file is compiled as two code objects (build.py): -DWD_MLP_PART=1 the rollout's kernels (policy forward, record),
+// -DWD_MLP_PART=2 the update's (returns, objective, the backward passes): half the compile time each, side by side.
+#if !defined(WD_MLP_PART) || WD_MLP_PART == 2
 WD_WEIGHT_GRAD(256, 256, 2, 2)
 WD_WEIGHT_GRAD(256, 96, 4, 1)
 WD_MLP_MASK_BACKWARD(256)
 WD_MLP_MASK_BACKWARD(128)
 WD_MLP_MASK_BACKWARD(64)
+#endif
+#if !defined(WD_MLP_PART) || WD_MLP_PART == 1
 WD_MLP_KERNEL(256, 256, 1)
 WD_MLP_KERNEL(256, 256, 2)
 WD_MLP_KERNEL(256, 256, 3)
@@ -1217,7 +1222,9 @@ WD_MLP_KERNEL(128, 128, 3)
 WD_MLP_KERNEL(64, 64, 1)
 WD_MLP_KERNEL(64, 64, 2)
 WD_MLP_KERNEL(64, 64, 3)
+#endif
 
+#if !defined(WD_MLP_PART) || WD_MLP_PART == 1
 // HipRolloutRecord: the trainer's per-tick bookkeeping as ONE launch (it used to be ~20 framework kernels per tick:
 // index_select / index_copy_ per policy and array, the episodic-reward sums -- 100 us of the 670 us tick at
 // configs[2]).  After the env tick: row t of every policy's reward batch and of the done batch, the running episodic
@@ -1264,6 +1271,8 @@ __global__ void HipRolloutRecord(const float *__restrict__ rewards, const int *_
   if (tid == 0) batch_row[e] = t + 1;
 }
 
+#endif  // WD_MLP_PART 1
+#if !defined(WD_MLP_PART) || WD_MLP_PART == 2
 // HipDiscountedReturns: the bootstrapped discounted returns of a training batch (reference a2c.py:80-95),
 //     R[T-1] = done[T-1] ? r[T-1] : V[T-1],   R[t] = r[t] + ((1 - done[t]) * gamma) * R[t+1]
 // one thread per (replica, agent) walking its T steps backwards; V = column `v_col` of the network's output rows of width
@@ -1426,4 +1435,5 @@ WD_HEAD_BACKWARD_BX3(3)
 WD_HEAD_BACKWARD(43)
 WD_HEAD_BACKWARD(6)
 WD_HEAD_BACKWARD(3)
+#endif  // WD_MLP_PART 2
 }
