@@ -597,3 +597,43 @@ def test_discounted_returns_kernel_is_bit_identical(T, E, n, W):
         want = discounted_returns(rewards, done, out[..., -1], gamma)
         assert torch.equal(got, want)
         assert torch.equal(adv, want - out[..., -1])
+
+
+def test_unit_gradient_shortcut_is_loss_backward():
+    """`torch.autograd.backward(loss, grad_tensors=unit_gradient(...))` (what the trainer calls) = `loss.backward()`: same
+    gradient bit for bit, and FusedObjective.backward recognised the unit tensor (no multiplication pass); a scaled loss
+    still takes the multiplication"""
+    from tests.hip_harness import require_gpu
+    from warp_drive_amd.managers.function_manager import HIPFunctionManager
+    from warp_drive_amd.training import update_kernels
+    from warp_drive_amd.training.losses import A2C
+
+    require_gpu()
+    fm = HIPFunctionManager(num_agents=1, num_envs=1)
+    fm.load_hip_from_binary_file()
+    assert update_kernels.install(fm) is not None
+    torch.manual_seed(5)
+    T, E, n, heads = 6, 40, 7, (5, 3)
+    W = sum(heads) + 1
+    dev = torch.device("cuda:0")
+    base = torch.randn(T, E, n, W, device=dev)
+    actions = torch.stack([torch.randint(0, a, (T, E, n), device=dev) for a in heads], dim=-1).to(torch.int32)
+    rewards = torch.randn(T, E, n, device=dev)
+    done = (torch.rand(T, E, device=dev) < 0.1).to(torch.int32)
+    obj = A2C(discount_factor_gamma=0.98, vf_loss_coeff=0.5, entropy_coeff=0.02)
+    grads = []
+    for mode in ("backward", "unit", "scaled"):
+        out = base.clone().requires_grad_(True)
+        loss, _ = obj.compute_loss_and_metrics_from_logits(0, out, actions, rewards, done, heads, False)
+        hits = update_kernels.STATS["unit_gradient_hits"]
+        if mode == "backward":
+            loss.backward()
+        elif mode == "unit":
+            torch.autograd.backward(loss, grad_tensors=update_kernels.unit_gradient(dev))
+            assert update_kernels.STATS["unit_gradient_hits"] == hits + 1
+        else:
+            (2.0 * loss).backward()
+            assert update_kernels.STATS["unit_gradient_hits"] == hits
+        grads.append(out.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert torch.equal(grads[2], 2.0 * grads[0])

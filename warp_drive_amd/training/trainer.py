@@ -457,7 +457,8 @@ class Trainer:
             batch = self.batch[pol]
             if self._fused_update and self.neg_pos_env_ratio <= 0:
                 # the objective and its gradient with respect to the network's output as ONE kernel, the ReLU masks and
-                # bias gradients of the backward as one pass each (training/update_kernels.py); the GEMMs are the framework's
+                # bias gradients of the backward as one pass each (training/update_kernels.py), and for two 256-wide float32
+                # hidden layers the matrix products of the backward as well
                 stored = self._stored
                 if stored is not None and stored.get(pol) is not None and self._rollout_filled_stored:
                     # the forward pass is a read: the rollout's forward kernel stored these rows' activations and outputs
@@ -469,7 +470,7 @@ class Trainer:
                 loss, m = self.trainers[pol].compute_loss_and_metrics_from_logits(
                     self.current_timestep[pol], out.float(), batch["actions"][: self.batch_len],
                     batch["rewards"][: self.batch_len], done[: self.batch_len], self.head_sizes, log)
-                loss.backward()
+                torch.autograd.backward(loss, grad_tensors=update_kernels.unit_gradient(loss.device))  # = loss.backward()
                 if log:
                     metrics[pol] = m
                 continue

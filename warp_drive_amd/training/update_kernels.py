@@ -268,4 +268,23 @@ class FusedObjective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
         (grad,) = ctx.saved_tensors
+        if g_loss.data_ptr() == unit_gradient(grad.device).data_ptr():
+            STATS["unit_gradient_hits"] += 1
+            return grad, None, None, None, None, None, None, None   # d loss / d loss = 1, known without reading it
         return grad * g_loss.to(grad.dtype), None, None, None, None, None, None, None
+
+
+_UNIT = {}
+STATS = {"unit_gradient_hits": 0}   # (tests: the shortcut above was taken)
+
+
+def unit_gradient(device):
+    """THE float32 scalar 1.0 of `device`: `torch.autograd.backward(loss, grad_tensors=unit_gradient(loss.device))` is
+    `loss.backward()`, except that FusedObjective.backward recognises the tensor by its address and skips the pass that
+    would multiply the [rows, outputs] gradient by it (0.55 ms at configs[2]; it cannot look at the VALUE of an incoming
+    gradient without a host synchronisation).  Any other incoming gradient -- a scaled loss, a sum of losses -- takes the
+    multiplication."""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT[key]
