@@ -507,7 +507,10 @@ def test_head_backward_kernel(R, W, C):
     w3 = torch.randn(W, C, device="cuda") * 0.2
     h2 = torch.relu(torch.randn(R, C, device="cuda"))
     assert k.supports_head_backward(g3, w3, h2)
-    g2, db2, dw3 = k.head_backward(g3, w3, h2)
+    g2, db2, dw3, db3 = k.head_backward(g3, w3, h2)
+    assert (db3 is not None) == (C == 256 and R >= 65536)
+    if db3 is not None:
+        assert torch.allclose(db3, g3.double().sum(0).float(), rtol=1e-4, atol=1e-2)
     ref_g2 = torch.ops.aten.threshold_backward((g3.double() @ w3.double()).float(), h2, 0)
     assert torch.equal(g2 != 0, ref_g2 != 0) or float(((g2 != 0) != (ref_g2 != 0)).float().mean()) < 1e-6
     assert torch.allclose(g2, ref_g2, rtol=1e-5, atol=1e-5)

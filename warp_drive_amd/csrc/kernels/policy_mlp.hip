@@ -996,14 +996,16 @@ __device__ __forceinline__ void head_backward_impl(const float *__restrict__ g3,
 //                                   g3 rows, lane = row, 8 consecutive k (reads past a row's W values meet zero weights);
 //                                   masked with h2 read back from the stage in accumulator layout, stored, and summed per
 //                                   lane into the bias-gradient partials (reduced across rows once, at the end);
+//   db3 [W] += column sums of the step's g3 (8 rows per wavefront): the output layer's bias gradient rides along;
 //   dW3 tile [W (<= 64) x 64 units] += g3^T . h2  contraction over the step's 32 rows: both operands are read from the
 //                                   stage TRANSPOSED (lane = column, 8 consecutive rows), as in weight_grad_bx3.
 // R and rows_per_block are multiples of 32 (the caller runs the last R % 32 rows through the framework).
 template <int W, int NS>
 __device__ __forceinline__ void head_backward_bx3(const float *__restrict__ g3, const mlp_bf8 *__restrict__ w3pk,
                                                   const float *__restrict__ h2, float *__restrict__ g2,
-                                                  float *__restrict__ db2_part, float *__restrict__ dw3_part, long R,
-                                                  long rows_per_block, unsigned char *lds) {
+                                                  float *__restrict__ db2_part, float *__restrict__ dw3_part,
+                                                  float *__restrict__ db3_part, long R, long rows_per_block,
+                                                  unsigned char *lds) {
   constexpr int C = 256, ROW = C + 4, KS = (W + 15) / 16, OT = (W + 31) / 32;
   constexpr int G3MAX = 31 * W + (32 * OT > 16 * KS ? 32 * OT : 16 * KS) - 1;  // the last float of the stage any lane reads
   constexpr int G3P = G3MAX / 256 + 1;                                             // KB pieces of g3 per step
@@ -1044,6 +1046,7 @@ __device__ __forceinline__ void head_backward_bx3(const float *__restrict__ g3, 
 #pragma unroll
       for (int term = 0; term < 3; ++term) w3r[t][ks][term] = w3pk[(((wave * 2 + t) * KS + ks) * 3 + term) * 64 + lane];
   mlp_v16 accw[OT][2], gsum[2];
+  float g3sum = 0.0f;  // lane k < W: column k of g3 over this wavefront's 8 rows of every step (the output layer's bias gradient)
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -1106,6 +1109,10 @@ __device__ __forceinline__ void head_backward_bx3(const float *__restrict__ g3, 
 #pragma unroll
           for (int ut = 0; ut < 2; ++ut)
             accw[ot][ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g3a[ot][kk][GT[m]], h2b[ut][kk][XT[m]], accw[ot][ut], 0, 0, 0);
+    if (lane < W) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) g3sum += g3s[(8 * wave + r) * W + lane];
+    }
     // ---- mask, store, bias partials: accumulator register 4 q + e of lane (c, h) = unit 8 q + 4 h + e of the tile, row c
     float *const orow = g2 + (r0 + c) * C + 64 * wave + 4 * h;
     const float *const hrow = h2s + c * ROW + 64 * wave + 4 * h;
@@ -1135,6 +1142,7 @@ __device__ __forceinline__ void head_backward_bx3(const float *__restrict__ g3, 
         const int k = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (k < W) dw3_part[((long)blockIdx.x * W + k) * C + 64 * wave + 32 * ut + c] = accw[ot][ut][i];
       }
+  if (lane < W) db3_part[((long)blockIdx.x * 4 + wave) * W + lane] = g3sum;
   // bias partials: sum over the 32 rows (lanes c) of every (tile, register, h), through LDS -- once the LDS-direct loads of
   // the steps past the slab's end (issued to keep the wait counts uniform) have landed in the stages this reuses
   wg_wait_loads<0>();
@@ -1415,10 +1423,10 @@ __global__ void __launch_bounds__(256) HipReluBackwardColumnSums(const float *__
 #define WD_HEAD_BACKWARD_STAGES 3
 #define WD_HEAD_BACKWARD_BX3(WW)                                                                                      \
   __global__ void __launch_bounds__(256, 1) HipHeadBackwardBx3_W##WW(const float *g3, const void *w3pk, const float *h2, \
-                                                                     float *g2, float *db2_part, float *dw3_part, long R, \
-                                                                     long rows_per_block) {                             \
+                                                                     float *g2, float *db2_part, float *dw3_part,       \
+                                                                     float *db3_part, long R, long rows_per_block) {    \
     extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];                                          \
-    head_backward_bx3<WW, WD_HEAD_BACKWARD_STAGES>(g3, (const mlp_bf8 *)w3pk, h2, g2, db2_part, dw3_part, R,           \
+    head_backward_bx3<WW, WD_HEAD_BACKWARD_STAGES>(g3, (const mlp_bf8 *)w3pk, h2, g2, db2_part, dw3_part, db3_part, R, \
                                                    rows_per_block, mlp_smem);                                         \
   }
 WD_HEAD_BACKWARD_BX3(43)

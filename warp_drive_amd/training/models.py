@@ -227,12 +227,14 @@ class _TailHead(torch.autograd.Function):
         h1_2d, w2, w3, h2 = ctx.saved_tensors
         g3 = g.reshape(-1, g.shape[-1])
         kernels = update_kernels.active()
+        gb3 = None
         if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
-            g2, gb2, gw3 = kernels.head_backward(g3, w3, h2)
+            g2, gb2, gw3, gb3 = kernels.head_backward(g3, w3, h2)
         else:
             g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
             gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
-        gb3 = _column_sums(g3)
+        if gb3 is None:
+            gb3 = _column_sums(g3)
         gw2 = _weight_grad(g2, h1_2d)
         gh1 = (g2 @ w2).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
         return gh1, gw2, gb2, gw3, gb3, None, None
@@ -267,12 +269,14 @@ class _MlpTwoHidden(torch.autograd.Function):
         x2, w2, w3, h1, h2 = ctx.saved_tensors
         g3 = g.reshape(-1, g.shape[-1])
         kernels = update_kernels.active()
+        gb3 = None
         if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
-            g2, gb2, gw3 = kernels.head_backward(g3, w3, h2)
+            g2, gb2, gw3, gb3 = kernels.head_backward(g3, w3, h2)
         else:
             g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
             gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
-        gb3 = _column_sums(g3)
+        if gb3 is None:
+            gb3 = _column_sums(g3)
         gw2 = _weight_grad(g2, h1)
         if kernels is not None and kernels.supports_linear_mask_backward(g2, w2, h1):
             g1 = kernels.linear_mask_backward(g2, w2, h1)

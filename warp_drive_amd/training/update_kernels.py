@@ -97,7 +97,8 @@ class UpdateKernels:
 
     def head_backward(self, g3, w3, h2):
         """g3 [R, W] = d loss / d out, w3 [W, C] (all heads' rows, then the value's), h2 [R, C] = relu(...) ->
-        (g2 [R, C] = (g3 @ w3) * [h2 > 0], db2 [C] = its column sums, dw3 [W, C] = g3^T @ h2) in one pass"""
+        (g2 [R, C] = (g3 @ w3) * [h2 > 0], db2 [C] = its column sums, dw3 [W, C] = g3^T @ h2, db3 [W] = the column sums of
+        g3 or None where the kernel does not produce them) in one pass"""
         R, C = h2.shape
         W = w3.shape[0]
         if C == 256 and R >= self.WEIGHT_GRAD_MIN_ROWS:
@@ -112,7 +113,7 @@ class UpdateKernels:
         db2 = torch.empty((blocks, C), dtype=torch.float32, device=h2.device)
         dw3 = torch.empty((blocks, W, C), dtype=torch.float32, device=h2.device)
         fn(g3, w3, h2, g2, db2, dw3, np.int64(R), np.int32(self.ROWS_PER_BLOCK), block=(C, 1, 1), grid=(blocks, 1), shared=0)
-        return g2, db2.sum(dim=0), dw3.sum(dim=0)
+        return g2, db2.sum(dim=0), dw3.sum(dim=0), None
 
 
     HEAD_BACKWARD_STAGES = 3   # WD_HEAD_BACKWARD_STAGES of the kernel source
@@ -144,17 +145,19 @@ class UpdateKernels:
         g2 = torch.empty_like(h2)
         db2 = torch.empty((blocks, C), dtype=torch.float32, device=h2.device)
         dw3 = torch.empty((blocks, W, C), dtype=torch.float32, device=h2.device)
+        db3 = torch.empty((blocks * 4, W), dtype=torch.float32, device=h2.device)
         g3_max = 31 * W + max(32 * ((W + 31) // 32), 16 * ks) - 1
         g3_floats = 1024 * ((g3_max // 256 + 1 + 3) // 4)
-        fn(g3, w3pk, h2, g2, db2, dw3, np.int64(main), np.int64(rows_per_block), block=(256, 1, 1), grid=(blocks, 1),
+        fn(g3, w3pk, h2, g2, db2, dw3, db3, np.int64(main), np.int64(rows_per_block), block=(256, 1, 1), grid=(blocks, 1),
            shared=self.HEAD_BACKWARD_STAGES * 4 * (g3_floats + 32 * 260))
-        db2, dw3 = db2.sum(dim=0), dw3.sum(dim=0)
+        db2, dw3, db3 = db2.sum(dim=0), dw3.sum(dim=0), db3.sum(dim=0)
         if main < R:
             tail = torch.ops.aten.threshold_backward(g3[main:] @ w3, h2[main:], 0)
             g2[main:] = tail
             db2 = db2 + tail.sum(dim=0)
             dw3 = dw3 + g3[main:].t() @ h2[main:]
-        return g2, db2, dw3
+            db3 = db3 + g3[main:].sum(dim=0)
+        return g2, db2, dw3, db3
 
     # ------------------------------------------------ a hidden layer's input gradient + the mask of the layer under it
     def supports_linear_mask_backward(self, g_in, w, h):
