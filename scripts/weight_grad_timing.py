@@ -19,6 +19,9 @@ hh = torch.relu(h)
 print("mask backward %.2f ms" % t(lambda: k.linear_mask_backward(g, w2, hh)))
 g3 = torch.randn(R, 43, device="cuda"); w3 = torch.randn(43, 256, device="cuda") * 0.2
 print("head backward %.2f ms" % t(lambda: k.head_backward(g3, w3, hh)))
+out43 = torch.randn(R, 43, device="cuda"); acts = torch.randint(0, 21, (R, 2), device="cuda", dtype=torch.int32)
+adv = torch.randn(R, device="cuda"); ret = torch.randn(R, device="cuda")
+print("objective %.2f ms" % t(lambda: k.policy_gradient_head(out43, acts, adv, ret, (21, 21), 0.05, 1.0)))
 if len(sys.argv) > 1:
     sys.exit(0)
 def bmm(a, b):
