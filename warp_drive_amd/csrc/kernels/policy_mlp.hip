@@ -1331,7 +1331,14 @@ __global__ void __launch_bounds__(256) HipPolicyGradientHead(const float *__rest
   const long row0 = (long)blockIdx.x * 256;
   const int rows = (int)min((long)256, (long)R - row0);
   const int n = rows * W;
-  for (int q = tid; q < n; q += 256) tile[q] = out[row0 * W + q];
+  // the block's rows are one contiguous run: 16-byte vectors where the run is aligned (whole blocks of a contiguous tensor:
+  // 256 W floats), single floats otherwise -- a dword per lane and instruction made the copies, not the arithmetic, the
+  // kernel's time
+  const float *const src = out + row0 * W;
+  float *const dst = grad + row0 * W;
+  const int n4 = ((((size_t)src | (size_t)dst) & 15) == 0) ? n >> 2 : 0;
+  for (int q = tid; q < n4; q += 256) ((float4 *)tile)[q] = ((const float4 *)src)[q];
+  for (int q = 4 * n4 + tid; q < n; q += 256) tile[q] = src[q];
   __syncthreads();
   float s_pg = 0.0f, s_ent = 0.0f, s_vf = 0.0f, s_adv = 0.0f;
   if (tid < rows) {
@@ -1368,7 +1375,8 @@ __global__ void __launch_bounds__(256) HipPolicyGradientHead(const float *__rest
     s_adv = a;
   }
   __syncthreads();
-  for (int q = tid; q < n; q += 256) grad[row0 * W + q] = tile[q];
+  for (int q = tid; q < n4; q += 256) ((float4 *)dst)[q] = ((const float4 *)tile)[q];
+  for (int q = 4 * n4 + tid; q < n; q += 256) dst[q] = tile[q];
   // block sums (wave shuffles, then the four wavefronts' partials through LDS, in a fixed order: deterministic)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
