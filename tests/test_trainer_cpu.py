@@ -260,3 +260,109 @@ def test_reference_checkpoint_wire_format():
         for h, p in enumerate(probs):
             np.testing.assert_allclose(p.numpy(), g[f"{pol}.probs{h}"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(vals.numpy(), g[f"{pol}.values"], rtol=1e-6, atol=1e-6)
+
+
+def test_update_plan_names_what_runs_and_what_falls_back():
+    """`UpdateKernels.update_plan` (logged once at trainer start): a float32 [256, 256] policy at a BASELINE-sized batch is
+    served end to end by the hand-written kernels; below 65 536 rows, for other widths / depths and under autocast the steps
+    that fall back to the framework say so.  (Predicates only: no GPU, nothing allocated.)"""
+    from warp_drive_amd.training.update_kernels import UpdateKernels, _ShapeOnly
+
+    k = UpdateKernels.__new__(UpdateKernels)   # (the predicates do not touch the function manager)
+    orig = UpdateKernels.update_plan
+
+    def plan(model, rows, autocast=False):   # stand in for a CUDA model: the predicates ask `is_cuda` of their tensors
+        import warp_drive_amd.training.update_kernels as uk
+
+        saved = uk._ShapeOnly
+        try:
+            uk._ShapeOnly = lambda shape, dev: saved(shape, "cuda:0")
+            return orig(k, model, rows, autocast)
+        finally:
+            uk._ShapeOnly = saved
+
+    big = plan(FullyConnected(71, [21, 21], (256, 256)), 250 * 2000 * 100)
+    assert big == {"objective": "HipPolicyGradientHead", "output layer backward + mask + bias": "HipHeadBackwardBx3_W43",
+                   "dW2": "HipWeightGradBx3_256x256", "input gradient of layer 2 + mask": "HipLinearMaskBackwardBx3_256",
+                   "dW1 + db1": "HipWeightGradBx3_256x96"}
+    small = plan(FullyConnected(71, [21, 21], (256, 256)), 13050)
+    assert small["output layer backward + mask + bias"] == "HipHeadBackward_W43" and small["dW2"] == "framework" \
+        and small["dW1 + db1"] == "framework" and small["input gradient of layer 2 + mask"] == "HipLinearMaskBackwardBx3_256"
+    other = plan(FullyConnected(21, [5], (32, 32)), 10 ** 6)
+    assert other["output layer backward + mask + bias"] == "framework" and other["dW2"] == "framework"
+    assert "framework" in plan(FullyConnected(71, [21, 21], (256, 256)), 10 ** 7, autocast=True)["backward"]
+    assert "framework" in plan(FullyConnected(71, [21, 21], (256,)), 10 ** 7)["hidden layers below the last"]
+    assert _ShapeOnly((3, 4), "cpu").is_contiguous() and _ShapeOnly((3, 4), "cpu").dim() == 2
+
+
+def test_policy_without_hidden_layers_and_the_private_gemm_epilogue():
+    """`fc_dims: []` is the output layer alone on both entry points (forward_logits raised KeyError '-1' once); and the one
+    private torch entry point on the recomputing path, `torch._addmm_activation(bias, x, w.T, use_gelu=False)`, is pinned:
+    if its signature or meaning changes this fails loudly here instead of `_linear_relu` silently switching form."""
+    from warp_drive_amd.training import models
+
+    torch.manual_seed(3)
+    m = FullyConnected(9, [4, 3], [])
+    x = torch.randn(5, 2, 9)
+    probs, values = m(x)
+    logits = m.forward_logits(x)
+    assert logits.shape == (5, 2, 8)
+    np.testing.assert_allclose(torch.softmax(logits[..., :4], -1).detach().numpy(), probs[0].detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(logits[..., 7].detach().numpy(), values.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert hasattr(torch, "_addmm_activation"), "torch._addmm_activation is gone: give models._linear_relu a new fused form"
+    w, b, xx = torch.randn(6, 9), torch.randn(6), torch.randn(11, 9)
+    fused = torch._addmm_activation(b, xx, w.t(), use_gelu=False)
+    assert torch.allclose(fused, torch.relu(torch.nn.functional.linear(xx, w, b)), rtol=1e-6, atol=1e-6)
+    assert torch.equal(models._linear_relu(xx, w, b), torch.relu(torch.nn.functional.linear(xx, w, b)))  # (CPU: plain form)
+
+
+def test_parameter_versions_see_every_unannounced_change():
+    """what the stored-activation guard of the trainer relies on: an optimizer step, `load_state_dict` and a manual
+    in-place edit each advance a parameter's version counter; reading the parameters does not"""
+    from warp_drive_amd.training.policy_kernel import parameter_versions
+
+    m = FullyConnected(7, [3], (8, 8))
+    v0 = parameter_versions(m)
+    m(torch.randn(4, 7))[1].sum().backward()
+    assert parameter_versions(m) == v0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.step()
+    v1 = parameter_versions(m)
+    assert all(b > a for a, b in zip(v0, v1))
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    v2 = parameter_versions(m)
+    assert all(b > a for a, b in zip(v1, v2))
+    with torch.no_grad():
+        m.fc["1"][0].bias.add_(1.0)
+    v3 = parameter_versions(m)
+    assert sum(b > a for a, b in zip(v2, v3)) == 1
+
+
+def test_inference_copies_are_refreshed_in_place():
+    """`forward_inference` keeps cast / concatenated copies of the weights; a rollout tick captured in a hipGraph reads them
+    at fixed addresses, so `refresh_inference_cache` (called after every optimizer step) must update the SAME tensors --
+    replacing them left a replayed tick on stale head weights (round 6: Cartpole on the per-tick path un-learned)."""
+    torch.manual_seed(1)
+    m = FullyConnected(4, [2], (32, 32))
+    x = torch.randn(6, 1, 4)
+    for dtype in (None, torch.bfloat16):
+        m.forward_inference(x, dtype=dtype)
+    heads = {dt: m._inference_cache[dt]["head"] for dt in (None, torch.bfloat16)}
+    ptrs = {dt: (w.data_ptr(), b.data_ptr()) for dt, (w, b) in heads.items()}
+    opt = torch.optim.SGD(m.parameters(), lr=0.5)
+    m.forward_logits(x).square().sum().backward()
+    opt.step()
+    m.refresh_inference_cache()
+    for dt in (None, torch.bfloat16):
+        w, b = m._inference_cache[dt]["head"]
+        assert (w.data_ptr(), b.data_ptr()) == ptrs[dt] and w is heads[dt][0]
+    want = torch.cat([h.weight for h in m.policy_head] + [m.vf_head.weight], dim=0)
+    assert torch.equal(heads[None][0], want) and torch.equal(heads[torch.bfloat16][0], want.to(torch.bfloat16))
+    probs_i, vals_i = m.forward_inference(x)
+    probs, vals = m(x)
+    assert torch.allclose(probs_i[0], probs[0], atol=1e-6) and torch.allclose(vals_i, vals, atol=1e-6)
+    # an unannounced in-place change is still seen (version counters) the next time the host runs the forward
+    with torch.no_grad():
+        m.vf_head.bias.add_(1.0)
+    assert torch.allclose(m.forward_inference(x)[1], vals + 1.0, atol=1e-6)
+    assert m._inference_cache[None]["head"][0].data_ptr() == ptrs[None][0]

@@ -144,6 +144,12 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
 
     ROLLOUT_POLICY_WIDTHS = (32, 64)   # HipClassicControlCartPoleEnvRollout_H<width>
 
+    def has_live_policy_rollout(self, width, n_actions):
+        """does a rollout kernel exist that evaluates the policy network itself (…Rollout_H<width>)?  (RolloutEngine asks
+        before it calls `tick_launch(policy=...)`)"""
+        name = self.cuda_step.name.replace("Step", f"Rollout_H{int(width)}")
+        return int(width) in self.ROLLOUT_POLICY_WIDTHS and int(n_actions) <= 8 and self.cuda_function_manager.has_function(name)
+
     def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None, policy=None):
         """Fused rollout tick(s): sample + step + reset of a finished replica, `ticks_per_launch`
         times in ONE launch (HipClassicControlCartPoleEnvTick).  probabilities = [float32 CUDA tensor
@@ -163,7 +169,10 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
         if policy is not None:
             packed, width = policy
             n_act = int(probabilities[0].shape[-1])
-            assert width in self.ROLLOUT_POLICY_WIDTHS and n_act <= 8
+            if not self.has_live_policy_rollout(width, n_act):
+                from warp_drive_amd.rollout import UnsupportedRolloutShape
+
+                raise UnsupportedRolloutShape(f"no in-kernel policy of width {width} with {n_act} actions")
             n_w = 4 * width + width + width * width + width + n_act * width + n_act
             assert packed.is_cuda and packed.dtype.is_floating_point and packed.numel() == n_w and packed.is_contiguous()
             name = self.cuda_step.name.replace("Step", f"Rollout_H{width}")

@@ -204,6 +204,14 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
         runner (run_configs/tag_gridworld.yaml maps them to the "tagger" / "runner" policies)"""
         return [list(range(self.num_agents - 1)), [self.num_agents - 1]]
 
+    def has_live_policy_rollout(self, width, n_actions):
+        """does a rollout kernel exist that evaluates the two policy networks itself (HipTagGridWorldRollout_N5_H<width>)
+        for this env shape?  5 agents, full observations, 5 actions, hidden width 32 / 64 (RolloutEngine asks before it
+        calls `tick_launch(policy=...)`)"""
+        return (int(width) in self.ROLLOUT_POLICY_WIDTHS and int(n_actions) == 5 and len(self.step_actions) == 5
+                and self._specialised_rollout_shape()
+                and self.cuda_function_manager.has_function(f"HipTagGridWorldRollout_N5_H{int(width)}"))
+
     def tick_launch(self, sampler, probabilities, resetter, env_range=None, batch=None, policy=None):
         """Fused rollout tick: sample the action + step + reset finished replicas in ONE launch
         (HipTagGridWorldTick).  probabilities = [float32 CUDA tensor [E, N, n_actions]].  `_done_`
@@ -256,9 +264,12 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
             args += [np.int32(T), batch["obs"], batch["actions"], batch["rewards"], batch["done"], np.int32(cache_dwords)]
             special = self._specialised_rollout(name, block, cache_dwords)
             if policy is not None:
+                from warp_drive_amd.rollout import UnsupportedRolloutShape
+
                 (tagger, runner), width = policy
-                assert special is not None, "the live-policy rollout exists for 5 agents with full observations only"
-                assert width in self.ROLLOUT_POLICY_WIDTHS and int(probabilities[0].shape[-1]) == 5
+                if special is None or not self.has_live_policy_rollout(width, int(probabilities[0].shape[-1])):
+                    raise UnsupportedRolloutShape("the live-policy rollout exists for 5 agents with full observations, "
+                                                  "5 actions and hidden widths 32 / 64 only")
                 n_w = gridworld_policy_floats(width)
                 for t in (tagger, runner):
                     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n_w
@@ -276,7 +287,10 @@ class _DeviceStepMixin(CUDAEnvironmentContext):
                 return (fm.get_function(special), args + [fm.global_address("kIndexToActionArr")], block, grid,
                         (lds5 + 15) // 16 * 16)
             return fm.get_function(name), args, block, grid, lds
-        assert policy is None, "the live-policy rollout needs ticks_per_launch > 1 and the batch tensors"
+        if policy is not None:
+            from warp_drive_amd.rollout import UnsupportedRolloutShape
+
+            raise UnsupportedRolloutShape("the live-policy rollout needs ticks_per_launch > 1 and the batch tensors")
         return fm.get_function(name), args, block, grid, self.lds_bytes(epb)
 
     SPECIALISED_ROLLOUT = os.environ.get("WD_GW_ROLLOUT_N5", "1") != "0"  # False: always the general rollout kernel

@@ -8,6 +8,7 @@ pycuda_function_manager.py:17-20).
 The product path has NO CPU fallback: if the library or the code object is missing,
 or no GPU is visible, the calls raise HipDriverError.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -55,9 +56,14 @@ def reload_manifest():
 
 
 def code_object_of(kernel_name):
-    """path of the code object that holds `kernel_name`, or None when no object of the build has it"""
+    """path of the code object that holds `kernel_name`, or None when no object of the build has it -- the manifest is
+    only a map: an entry whose file is not on disk (a partial build, `build_kernels(only=...)`, a failed unit) counts
+    as "not built", so that capability queries answer False instead of failing later at module load"""
     name = manifest().get(kernel_name)
-    return None if name is None else code_object_path(name)
+    if name is None:
+        return None
+    path = code_object_path(name)
+    return path if os.path.exists(path) else None
 
 
 def code_object_sha256(kernel_name):
@@ -348,6 +354,11 @@ def _dim3(v, n=3):
     return v + (1,) * (n - len(v))
 
 
+# launches per kernel name through Function.__call__ (plans / graphs replay from C and are not counted): lets a test assert
+# WHICH kernels a composed path actually ran instead of trusting a dispatch predicate
+LAUNCH_COUNTS = collections.Counter()
+
+
 class Function:
     """A kernel.  Callable both ways the reference's env classes use
     (example_envs/tag_continuous/tag_continuous.py:842-851):
@@ -365,6 +376,7 @@ class Function:
         rc = _lib.wd_launch_packed(_vp(self.handle), g[0], g[1], g[2], b[0], b[1], b[2], int(shared),
                                    _vp(current_stream() if stream is None else stream), packed, len(packed))
         _check(rc, f"launch {self.name}")
+        LAUNCH_COUNTS[self.name] += 1
 
     def __getitem__(self, cfg):
         grid, block = cfg[0], cfg[1]

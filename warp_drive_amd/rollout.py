@@ -25,6 +25,12 @@ from warp_drive_amd.utils.spaces import Discrete, MultiDiscrete
 _ACTIONS = Constants.ACTIONS
 
 
+class UnsupportedRolloutShape(RuntimeError):
+    """an env's tick entry was asked for a variant (live in-kernel policy, presampled actions, ...) that does not exist
+    for this env shape -- a capability answer, raised explicitly (never an `assert`: it must survive `python -O` and must
+    not be confused with an assertion that caught a bug)"""
+
+
 class RolloutEngine:
     def __init__(self, env_wrapper, sampler: HIPSampler, probabilities=None, reset_done=True, fused=True,
                  rollout_batch=None, rollout_policy=None, ticks_per_launch=None, presampled_actions=False):
@@ -87,8 +93,14 @@ class RolloutEngine:
             extra = {"batch": rollout_batch} if rollout_batch is not None else {}
             if rollout_policy is not None:
                 extra["policy"] = rollout_policy
-            if self.presampled:
-                assert env_wrapper.env.has_presampled_tick(), "this env / shape has no step + reset entry for given actions"
+            if self.presampled and not env_wrapper.env.has_presampled_tick():
+                raise UnsupportedRolloutShape("this env / shape has no step + reset entry for given actions")
+            if rollout_policy is not None:
+                has = getattr(env_wrapper.env, "has_live_policy_rollout", None)
+                if has is None or not has(int(rollout_policy[1]), int(head_sizes[0])):
+                    raise UnsupportedRolloutShape(
+                        f"{type(env_wrapper.env).__name__} has no rollout kernel that evaluates a policy of hidden width "
+                        f"{rollout_policy[1]} for this shape")
             fn, args, block, grid, shared = env_wrapper.env.tick_launch(sampler, None if self.presampled else probabilities,
                                                                         env_wrapper.env_resetter, **extra)
             self.plan.add(fn, args, block, grid, shared)

@@ -116,18 +116,20 @@ class A2C:
                 metrics["Num of Negative Sampled Envs"] = len(neg_env_ids)
         return loss, metrics
 
-    def compute_loss_and_metrics_from_logits(self, timestep, out, actions_batch, rewards_batch, done_flags_batch, head_sizes, perform_logging):
+    def compute_loss_and_metrics_from_logits(self, timestep, out, actions_batch, rewards_batch, done_flags_batch, head_sizes,
+                                             perform_logging, kernels=None):
         """`compute_loss_and_metrics` on the network's raw output `out` [T, E, n, W] (logits of every head, then the value)
         with the objective and its gradient formed by ONE kernel (training/update_kernels.py::FusedObjective): same loss,
-        same gradient, same metric names.  The returns / advantages -- small [T, E, n] tensors -- are the code above."""
+        same gradient, same metric names.  The returns / advantages -- small [T, E, n] tensors -- are the code above.
+        `kernels`: the UpdateKernels of the caller's device (required: this entry IS the kernel path)."""
         from warp_drive_amd.training.update_kernels import FusedObjective
 
-        from warp_drive_amd.training import update_kernels
-
+        if kernels is None:
+            raise ValueError("compute_loss_and_metrics_from_logits needs the caller's UpdateKernels (kernels=...); "
+                             "the framework objective is compute_loss_and_metrics")
         values_detached = out[..., -1].detach()
-        kernels = update_kernels.active()
         out_d = out.detach()
-        if kernels is not None and kernels.supports_discounted_returns(rewards_batch, done_flags_batch, out_d):
+        if kernels.supports_discounted_returns(rewards_batch, done_flags_batch, out_d):
             # (one kernel instead of a Python loop over T of four small ones: launch-bound, ~1.3 ms per policy)
             returns, advantages = kernels.discounted_returns(rewards_batch, done_flags_batch, out_d, self.discount_factor_gamma)
         else:
@@ -140,7 +142,7 @@ class A2C:
         vf_c = self.vf_loss_coeff_schedule.get_param_value(timestep)
         ent_c = self.entropy_coeff_schedule.get_param_value(timestep)
         W = out.shape[-1]
-        loss, terms = FusedObjective.apply(out.reshape(-1, W), actions_batch.reshape(-1, actions_batch.shape[-1]).to(torch.int32).contiguous(),
+        loss, terms = FusedObjective.apply(kernels, out.reshape(-1, W), actions_batch.reshape(-1, actions_batch.shape[-1]).to(torch.int32).contiguous(),
                                            norm_adv.reshape(-1).contiguous(), norm_returns.reshape(-1).contiguous(),
                                            tuple(int(a) for a in head_sizes), float(ent_c), float(vf_c), self.clip_param is not None)
         metrics = {}

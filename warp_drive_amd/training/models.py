@@ -4,11 +4,12 @@ Mirror of reference warp_drive/training/models/{model_base,fully_connected}.py: 
 trunk, one softmax head per discrete action dimension and a scalar value head.  The
 observation tensor the step kernel writes is consumed IN PLACE (a gather of this policy's
 agent rows, no host copy; model_base.py:133-186)."""
+import logging
+
 import numpy as np
 import torch
 from torch import nn
 
-from warp_drive_amd.training import update_kernels
 from warp_drive_amd.utils.spaces import Box, Dict, Discrete, MultiDiscrete
 
 
@@ -39,26 +40,49 @@ class FullyConnected(nn.Module):
         self.policy_head = nn.ModuleList([nn.Linear(dims[-1], int(a)) for a in head_sizes])
         self.vf_head = nn.Linear(dims[-1], 1)
         self.head_sizes = [int(a) for a in head_sizes]
-        self._inference_cache = {}  # dtype -> (trunk [(w, b)], concatenated head (w, b)); see refresh_inference_cache
+        # the trainer's hand-written update kernels for THIS model (training/update_kernels.py::UpdateKernels, bound to the
+        # function manager -- hence the device -- of the trainer that owns the model) or None: the framework's operations.
+        # Carried by the model and handed to the autograd nodes below as an argument: there is no process-wide switch
+        self.update_kernels = None
+        self._inference_cache = {}  # dtype -> {trunk [(w, b)], head (w, b), versions}; see refresh_inference_cache
 
     def refresh_inference_cache(self):
-        """forget the cast / concatenated copies of the weights that forward_inference keeps (call after every
-        optimizer step or checkpoint load, as FusedPolicyForward.pack() is)"""
-        self._inference_cache = {}
+        """bring the cast / concatenated copies of the weights that forward_inference keeps up to date with the
+        parameters, IN PLACE (call after every optimizer step or checkpoint load, as FusedPolicyForward.pack() is).
+        In place because a rollout tick captured in a hipGraph keeps reading the copies at the addresses they had at
+        capture time: replacing the tensors (what this did until round 6) left a replayed tick on the head weights
+        of the capture -- the trunk aliases the live parameters -- i.e. a behaviour policy that is neither the old nor
+        the new network (found by tests/test_gpu_learning.py: Cartpole on the per-tick path un-learned)."""
+        for dtype in list(self._inference_cache):
+            self._fill_inference_cache(dtype)
+
+    @torch.no_grad()
+    def _fill_inference_cache(self, dtype):
+        cast = (lambda t: t.detach()) if dtype is None else (lambda t: t.detach().to(dtype))
+        trunk = [(cast(self.fc[str(i)][0].weight), cast(self.fc[str(i)][0].bias)) for i in range(len(self.fc))]
+        w = cast(torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0))
+        b = cast(torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0))
+        entry = self._inference_cache.get(dtype)
+        if entry is None or entry["head"][0].shape != w.shape or entry["head"][0].device != w.device:
+            entry = self._inference_cache[dtype] = {"trunk": trunk, "head": (w, b)}
+        else:
+            if dtype is not None:  # (dtype None: the trunk entries ARE the parameters)
+                for (dw, db), (sw, sb) in zip(entry["trunk"], trunk):
+                    dw.copy_(sw)
+                    db.copy_(sb)
+            entry["head"][0].copy_(w)
+            entry["head"][1].copy_(b)
+        entry["versions"] = tuple(int(p._version) for p in self.parameters())
+        return entry
 
     @torch.no_grad()
     def _inference_weights(self, dtype):
-        # keyed by the parameters' version counters too: an in-place update (optimizer step, checkpoint
-        # load) that nobody announced still invalidates the copies
-        key = (dtype, tuple(p._version for p in self.parameters()))
-        if key not in self._inference_cache:
-            self._inference_cache = {}
-            cast = (lambda t: t.detach()) if dtype is None else (lambda t: t.detach().to(dtype))
-            trunk = [(cast(self.fc[str(i)][0].weight), cast(self.fc[str(i)][0].bias)) for i in range(len(self.fc))]
-            w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
-            b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-            self._inference_cache[key] = (trunk, (cast(w), cast(b)))
-        return self._inference_cache[key]
+        # checked against the parameters' version counters too: an in-place update (optimizer step, checkpoint
+        # load) that nobody announced still refreshes the copies (in place) the next time the host runs this
+        entry = self._inference_cache.get(dtype)
+        if entry is None or entry["versions"] != tuple(int(p._version) for p in self.parameters()):
+            entry = self._fill_inference_cache(dtype)
+        return entry["trunk"], entry["head"]
 
     def forward(self, obs):
         """obs [..., obs_size] -> ([probs per head, each [..., A_h]], values [...]).
@@ -68,10 +92,10 @@ class FullyConnected(nn.Module):
         x = obs
         for i in range(len(self.fc)):
             lin = self.fc[str(i)][0]
-            x = _Affine.apply(x, lin.weight, lin.bias, True)
+            x = _Affine.apply(x, lin.weight, lin.bias, True, self.update_kernels)
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        out = _Affine.apply(x, w, b, False)
+        out = _Affine.apply(x, w, b, False, self.update_kernels)
         probs, start = [], 0
         for a in self.head_sizes:
             probs.append(torch.softmax(out[..., start:start + a], dim=-1))
@@ -81,20 +105,21 @@ class FullyConnected(nn.Module):
     def forward_logits(self, obs):
         """obs [..., obs_size] -> [..., sum(head_sizes) + 1]: the logits of every head, then the value -- what `forward`
         turns into probabilities; the fused objective (training/update_kernels.py) works on this tensor directly"""
-        x = obs
+        x, k = obs, self.update_kernels
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        fused_tail = not torch.is_autocast_enabled(obs.device.type) and obs.dtype == torch.float32
+        # (a network without hidden layers -- `fc_dims: []` -- is the output layer alone)
+        fused_tail = (not torch.is_autocast_enabled(obs.device.type) and obs.dtype == torch.float32 and len(self.fc) >= 1)
         if fused_tail and len(self.fc) == 2 and not obs.requires_grad:  # the usual network: one node, one planned backward
             l1, l2 = self.fc["0"][0], self.fc["1"][0]
-            return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, None, None, None)
+            return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, None, None, None, k)
         for i in range(len(self.fc) - (1 if fused_tail else 0)):
             lin = self.fc[str(i)][0]
-            x = _Affine.apply(x, lin.weight, lin.bias, True)
+            x = _Affine.apply(x, lin.weight, lin.bias, True, k)
         if fused_tail:  # the last hidden layer + the output layer: one node, one backward pass over h2
             last = self.fc[str(len(self.fc) - 1)][0]
-            return _TailHead.apply(x, last.weight, last.bias, w, b, None, None)
-        return _Affine.apply(x, w, b, False)
+            return _TailHead.apply(x, last.weight, last.bias, w, b, None, None, k)
+        return _Affine.apply(x, w, b, False, k)
 
     def forward_logits_stored(self, obs, h1, h2, out):
         """`forward_logits` without arithmetic: the rollout's forward kernel stored the hidden activations and the outputs
@@ -104,7 +129,7 @@ class FullyConnected(nn.Module):
         l1, l2 = self.fc["0"][0], self.fc["1"][0]
         w = torch.cat([h.weight for h in self.policy_head] + [self.vf_head.weight], dim=0)
         b = torch.cat([h.bias for h in self.policy_head] + [self.vf_head.bias], dim=0)
-        return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, h1, h2, out)
+        return _MlpTwoHidden.apply(obs, l1.weight, l1.bias, l2.weight, l2.bias, w, b, h1, h2, out, self.update_kernels)
 
     @torch.no_grad()
     def forward_inference(self, obs, dtype=None):
@@ -141,14 +166,13 @@ def _column_sums(g):
     return g.sum(dim=0, dtype=torch.float32)
 
 
-def _weight_grad(g, x):
+def _weight_grad(g, x, kernels=None):
     """g^T @ x for [rows, out] x [rows, in] with ~1e7 rows: one GEMM whose contraction is 1e7 long and
     whose result is 256 x 256 leaves most of the chip idle (5-10 ms at 1 TB/s on MI355X); as a batch of
     S independent slices of the rows followed by a sum over S it streams both operands at memory speed.
     float32 operands of the shapes HipWeightGradBx3_* covers go there instead (training/update_kernels.py::weight_grad:
     the batched GEMM already runs at the f32 matrix peak; bf16x3 arithmetic is what is left)."""
     rows = g.shape[0]
-    kernels = update_kernels.active()
     if kernels is not None and kernels.supports_weight_grad(g, x):
         return kernels.weight_grad(g, x)[0]
     if rows >= (1 << 20):
@@ -172,7 +196,7 @@ class _Affine(torch.autograd.Function):
     autocast dtype (bf16 matrix cores) with float32 parameters and float32 parameter gradients."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, kernels=None):
         dev = x.device.type
         dt = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
         x2 = x.reshape(-1, x.shape[-1]).to(dt)
@@ -180,7 +204,7 @@ class _Affine(torch.autograd.Function):
         with torch.autocast(device_type=dev, enabled=False):
             y = _linear_relu(x2, wc, bc) if relu else torch.addmm(bc, x2, wc.t())
         ctx.save_for_backward(x2, wc, y if relu else x2.new_empty(0))
-        ctx.relu, ctx.in_shape = bool(relu), x.shape
+        ctx.relu, ctx.in_shape, ctx.kernels = bool(relu), x.shape, kernels
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -188,18 +212,18 @@ class _Affine(torch.autograd.Function):
         x2, wc, y = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).to(x2.dtype)
         gb = None
+        kernels = ctx.kernels
         if ctx.relu:
-            kernels = update_kernels.active()
             if kernels is not None and kernels.supports_relu_backward(g2, y):
                 g2, gb = kernels.relu_backward_colsum(g2, y)  # mask + bias gradient in one pass over the gradient
             else:
                 g2 = torch.ops.aten.threshold_backward(g2, y, 0)
         with torch.autocast(device_type=g.device.type, enabled=False):
             gx = (g2 @ wc).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
-            gw = _weight_grad(g2, x2)
+            gw = _weight_grad(g2, x2, kernels)
             if gb is None:
                 gb = _column_sums(g2)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class _TailHead(torch.autograd.Function):
@@ -211,7 +235,7 @@ class _TailHead(torch.autograd.Function):
     nothing is computed going forward.  float32; the autocast update takes the per-layer `_Affine` path."""
 
     @staticmethod
-    def forward(ctx, h1, w2, b2, w3, b3, h2_stored, out_stored):
+    def forward(ctx, h1, w2, b2, w3, b3, h2_stored, out_stored, kernels=None):
         h1_2d = h1.reshape(-1, h1.shape[-1])
         if h2_stored is None:
             h2 = _linear_relu(h1_2d, w2, b2)
@@ -219,25 +243,25 @@ class _TailHead(torch.autograd.Function):
         else:
             h2, out = h2_stored.reshape(-1, w2.shape[0]), out_stored.reshape(-1, w3.shape[0])
         ctx.save_for_backward(h1_2d, w2, w3, h2)
-        ctx.in_shape = h1.shape
+        ctx.in_shape, ctx.kernels = h1.shape, kernels
         return out.view(*h1.shape[:-1], w3.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         h1_2d, w2, w3, h2 = ctx.saved_tensors
         g3 = g.reshape(-1, g.shape[-1])
-        kernels = update_kernels.active()
+        kernels = ctx.kernels
         gb3 = None
         if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
             g2, gb2, gw3, gb3 = kernels.head_backward(g3, w3, h2)
         else:
             g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
-            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
+            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2, kernels)
         if gb3 is None:
             gb3 = _column_sums(g3)
-        gw2 = _weight_grad(g2, h1_2d)
+        gw2 = _weight_grad(g2, h1_2d, kernels)
         gh1 = (g2 @ w2).reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        return gh1, gw2, gb2, gw3, gb3, None, None
+        return gh1, gw2, gb2, gw3, gb3, None, None, None
 
 
 class _MlpTwoHidden(torch.autograd.Function):
@@ -252,7 +276,7 @@ class _MlpTwoHidden(torch.autograd.Function):
     already known from the rollout (nothing is computed going forward) or None."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, h1_stored, h2_stored, out_stored):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, h1_stored, h2_stored, out_stored, kernels=None):
         x2 = x.reshape(-1, x.shape[-1])
         if h1_stored is None:
             h1 = _linear_relu(x2, w1, b1)
@@ -262,22 +286,23 @@ class _MlpTwoHidden(torch.autograd.Function):
             h1, h2 = h1_stored.reshape(-1, w1.shape[0]), h2_stored.reshape(-1, w2.shape[0])
             out = out_stored.reshape(-1, w3.shape[0])
         ctx.save_for_backward(x2, w2, w3, h1, h2)
+        ctx.kernels = kernels
         return out.view(*x.shape[:-1], w3.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         x2, w2, w3, h1, h2 = ctx.saved_tensors
         g3 = g.reshape(-1, g.shape[-1])
-        kernels = update_kernels.active()
+        kernels = ctx.kernels
         gb3 = None
         if kernels is not None and kernels.supports_head_backward(g3, w3, h2):
             g2, gb2, gw3, gb3 = kernels.head_backward(g3, w3, h2)
         else:
             g2 = torch.ops.aten.threshold_backward(g3 @ w3, h2, 0)
-            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2)
+            gb2, gw3 = _column_sums(g2), _weight_grad(g3, h2, kernels)
         if gb3 is None:
             gb3 = _column_sums(g3)
-        gw2 = _weight_grad(g2, h1)
+        gw2 = _weight_grad(g2, h1, kernels)
         if kernels is not None and kernels.supports_linear_mask_backward(g2, w2, h1):
             g1 = kernels.linear_mask_backward(g2, w2, h1)
         else:
@@ -285,26 +310,8 @@ class _MlpTwoHidden(torch.autograd.Function):
         if kernels is not None and kernels.supports_weight_grad(g1, x2, with_bias=True):
             gw1, gb1 = kernels.weight_grad(g1, x2, with_bias=True)  # (the bias gradient rides as a column of ones)
         else:
-            gb1, gw1 = _column_sums(g1), _weight_grad(g1, x2)
-        return None, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None
-
-
-class _AffineStored(torch.autograd.Function):
-    """`_Affine` whose forward result is already known (`y_stored`, same shape as the output): nothing is computed going
-    forward; the backward is `_Affine`'s, on the stored activations (float32 only)."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, relu, y_stored):
-        x2 = x.reshape(-1, x.shape[-1])
-        y2 = y_stored.reshape(-1, w.shape[0])
-        assert x2.dtype == torch.float32 and y2.dtype == torch.float32 and x2.shape[0] == y2.shape[0]
-        ctx.save_for_backward(x2, w, y2 if relu else x2.new_empty(0))
-        ctx.relu, ctx.in_shape = bool(relu), x.shape
-        return y_stored.view(*x.shape[:-1], w.shape[0])  # (a view: the stored rows are not copied)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (*_Affine.backward(ctx, g), None)
+            gb1, gw1 = _column_sums(g1), _weight_grad(g1, x2, kernels)
+        return None, gw1, gb1, gw2, gb2, gw3, gb3, None, None, None, None
 
 
 _FUSED_EPILOGUE = {"ok": hasattr(torch, "_addmm_activation")}  # decided once: a private torch entry point
@@ -317,6 +324,8 @@ def _linear_relu(x, weight, bias):
     if x.is_cuda and _FUSED_EPILOGUE["ok"]:
         try:
             return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
-        except Exception:  # noqa: BLE001 -- TypeError / NotImplementedError / RuntimeError alike
+        except Exception as err:  # noqa: BLE001 -- TypeError / NotImplementedError / RuntimeError alike
             _FUSED_EPILOGUE["ok"] = False
+            logging.warning(f"torch._addmm_activation failed ({type(err).__name__}: {err}); Linear + ReLU run as two "
+                            "operations from here on (tests/test_trainer_cpu.py pins the entry point's signature)")
     return torch.relu(torch.nn.functional.linear(x, weight, bias))

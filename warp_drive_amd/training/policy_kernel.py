@@ -64,6 +64,11 @@ def _bias_indices(n_tiles):
     return tn * 32 + _row_of(s, h)
 
 
+def parameter_versions(model):
+    """the in-place version counter of every parameter of `model`, in `parameters()` order"""
+    return tuple(int(p._version) for p in model.parameters())
+
+
 class FusedPolicyForward:
     HIDDEN = (64, 128, 256)
     MAX_OBS = 96
@@ -111,12 +116,17 @@ class FusedPolicyForward:
         self._bidx = [as_idx(_bias_indices(tn)), as_idx(_bias_indices(tn)), as_idx(_bias_indices(_OUT_TILES))]
         self._pads = [(tn * 32, self.kt1 * 32), (tn * 32, tn * 32), (_OUT_TILES * 32, tn * 32)]
         self.packed = None
+        self.packed_versions = None   # version counters of the model's parameters the packed copy was made from
         self._range_cache = {}
         self.pack()
 
     @torch.no_grad()
     def pack(self):
         m = self.model
+        # what the kernel will read is a COPY: remember which state of the parameters it is a copy of (every in-place
+        # change of a parameter -- optimizer step, load_state_dict, a manual edit -- advances its version counter), so
+        # that users of the kernel's results can tell whether they still belong to the model's current weights
+        self.packed_versions = parameter_versions(m)
         w3 = torch.cat([h.weight for h in m.policy_head] + [m.vf_head.weight], dim=0)
         b3 = torch.cat([h.bias for h in m.policy_head] + [m.vf_head.bias], dim=0)
         layers = [(m.fc["0"][0].weight, m.fc["0"][0].bias), (m.fc["1"][0].weight, m.fc["1"][0].bias), (w3, b3)]

@@ -26,14 +26,14 @@ import yaml
 
 from warp_drive_amd import distributed as wdd
 from warp_drive_amd.managers.function_manager import HIPSampler
-from warp_drive_amd.rollout import RolloutEngine
+from warp_drive_amd.rollout import RolloutEngine, UnsupportedRolloutShape
 from warp_drive_amd.training.data_loader import create_and_push_data_placeholders
 from warp_drive_amd.training.grad_bucket import GradientBucket
 from warp_drive_amd.training.losses import A2C, PPO
 from warp_drive_amd.training import update_kernels
 from warp_drive_amd.training.models import FullyConnected, action_head_sizes, flattened_obs_size
 from warp_drive_amd.training.policy_kernel import (FusedPolicyForward, FusedRolloutTick, pack_gridworld_policy, pack_rollout_policy,
-                                                    rollout_policy_width)
+                                                    parameter_versions, rollout_policy_width)
 from warp_drive_amd.utils.constants import Constants
 
 _ACTIONS, _REWARDS, _OBSERVATIONS = Constants.ACTIONS, Constants.REWARDS, Constants.OBSERVATIONS
@@ -219,17 +219,30 @@ class Trainer:
                                                                   arithmetic=str(tcfg.get("policy_arithmetic", "bf16x3")))
         self._ids32 = {pol: self.ids[pol].to(torch.int32) for pol in self.policies}
         # ---- the update's non-GEMM work as hand-written kernels (`trainer.fused_update`, default on; one or two heads)
-        self._fused_update = False
+        # The handle lives on THIS trainer and on its models (no process-wide switch: another trainer in the process with
+        # `fused_update: False`, or on another device, is unaffected).
+        self._fused_update, self._update_kernels, self.update_plan = False, None, {}
         if bool(tcfg.get("fused_update", True)) and self.device.type == "cuda" and len(self.head_sizes) <= 2 \
                 and sum(self.head_sizes) + 1 <= 64:
-            update_kernels.install(env_wrapper.cuda_function_manager)
+            self._update_kernels = update_kernels.UpdateKernels(env_wrapper.cuda_function_manager)
             self._fused_update = True
+            for pol in self.policies:
+                self.models[pol].update_kernels = self._update_kernels
+                if config["policy"][pol]["to_train"]:
+                    # on record, once: which steps of this policy's update run on the hand-written kernels and which fall
+                    # back to the framework (the kernels cover float32 networks of two 256-wide hidden layers fully)
+                    self.update_plan[pol] = self._update_kernels.update_plan(
+                        self.models[pol], self.batch_len * E * len(self.policy_map[pol]), autocast=self._update_dtype is not None)
+                    if self.rank == 0:
+                        update_kernels.UpdateKernels.log_update_plan(pol, self.update_plan[pol])
         # ---- the whole tick in THREE launches (`trainer.fused_tick`, default on): every policy's forward in one launch
         # with the actions drawn in its epilogue, the env's step + reset on those actions, the bookkeeping
         # (training/policy_kernel.py::FusedRolloutTick).  Needs: every policy on the fused forward with one network
         # shape, a two-head action space, and an env with a step + reset entry for given actions.
         self._fast_tick = None
-        self._stored, self._rollout_filled_stored = None, False
+        # `_stored_for`: per policy, the parameter versions the stored activations of the LAST rollout were computed with
+        # (= what the forward kernel's packed weights were a copy of), or absent: nothing stored
+        self._stored, self._stored_for = None, {}
         fw = [self._fused_forward[pol] for pol in self.policies]
         if (bool(tcfg.get("fused_tick", True)) and all(f is not None for f in fw) and len(fw) <= 2 and self.engine.fused
                 and len(self.head_sizes) == 2 and self.batch_len > 1 and self.actions.dtype == torch.int32
@@ -319,7 +332,7 @@ class Trainer:
             engine = RolloutEngine(env_wrapper, self.sampler, probabilities=self.probs, reset_done=True,
                                    rollout_batch=env_batch, rollout_policy=(arg, width),
                                    ticks_per_launch=self.batch_len)  # (the env object keeps its own setting)
-        except AssertionError as err:  # e.g. TagGridWorld with another shape: the kernel does not exist for it
+        except UnsupportedRolloutShape as err:  # e.g. TagGridWorld with another shape: the kernel does not exist for it
             logging.info(f"whole-batch rollout not available for this shape ({err}); using the per-tick path")
             return
         self.engine = engine
@@ -377,10 +390,36 @@ class Trainer:
         self._ep_cnt += finished
         b += 1
 
+    def _rollout_state_arrays(self):
+        """(address, bytes) of everything a rollout tick changes besides the batch rows it records: every device array of
+        the env's data manager except the [T, ...] batch placeholders, the sampler's generator state and the episodic
+        counters"""
+        dm = self.w.cuda_data_manager
+        arrays = [(int(p), int(p.nbytes)) for name, p in dm._device_data_pointer.items()
+                  if "_batch" not in name and int(p.nbytes) > 0]
+        rng = self.sampler.rng_state
+        arrays.append((int(rng), int(rng.nbytes)))
+        for t in [*self._ep_reward.values(), *self._ep_sum.values(), self._ep_cnt]:
+            arrays.append((int(t.data_ptr()), t.numel() * t.element_size()))
+        return arrays
+
     def _capture_tick_graph(self):
         """hipGraph of one tick (torch.cuda.CUDAGraph; the env kernel is launched through the C-ABI on
         the capturing stream and is recorded like any other node).  A rollout is then `batch_len`
-        graph replays: one host call per tick instead of ~70 framework dispatches."""
+        graph replays: one host call per tick instead of ~70 framework dispatches.
+
+        Capture needs a few REAL warm-up ticks (allocator, library handles).  They step the env, advance the generator
+        and accumulate into the episodic counters, so everything a tick changes is copied aside first and put back
+        afterwards: a run that replays the graph starts from exactly the state an eager run starts from (same seed, same
+        trajectory, same first logged "Mean episodic reward")."""
+        from warp_drive_amd.managers import hip_driver as drv
+
+        arrays = self._rollout_state_arrays()
+        offsets = np.cumsum([0] + [(n + 255) // 256 * 256 for _, n in arrays])
+        aside = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=self.device)
+        for (ptr, n), off in zip(arrays, offsets):
+            drv.memcpy_dtod(aside.data_ptr() + int(off), ptr, n)
+        graph = None
         try:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -395,11 +434,15 @@ class Trainer:
             with torch.cuda.graph(graph):
                 self._tick()
             torch.cuda.synchronize()
-            return graph
         except Exception as err:  # capture is an optimisation: fall back to eager ticks, loudly
             logging.warning(f"rollout tick could not be captured in a hipGraph ({err}); running it eagerly")
             torch.cuda.synchronize()
-            return None
+            graph = None
+        for (ptr, n), off in zip(arrays, offsets):   # the warm-up ticks never happened
+            drv.memcpy_dtod(ptr, aside.data_ptr() + int(off), n)
+        self._b_rows.zero_()
+        torch.cuda.synchronize()
+        return graph
 
     @torch.no_grad()
     def _generate_rollout_batch_in_one_launch(self):
@@ -442,8 +485,33 @@ class Trainer:
                 self._tick_graph.replay()
             else:
                 self._tick()
-        # (the stored activations belong to THIS batch and to the weights it was rolled out with)
-        self._rollout_filled_stored = self._fast_tick is not None and self._stored is not None
+        # the stored activations belong to THIS batch and to the weights the forward kernel read: the packed copy, made from
+        # the parameters at the versions recorded here.  The update compares them with the parameters' versions of its own
+        # moment: any change in between (load_state_dict, a manual edit, an optimizer step somebody else took) and it
+        # recomputes its forward pass instead of differentiating stale activations
+        self._stored_for = {}
+        if self._fast_tick is not None and self._stored is not None:
+            self._stored_for = {pol: self._fused_forward[pol].packed_versions for pol in self.policies
+                                if self._stored.get(pol) is not None}
+
+    @property
+    def _rollout_filled_stored(self):
+        """True while the last rollout's stored activations exist (whether they are still VALID is decided per policy at
+        update time: `_stored_activations_valid`)"""
+        return bool(self._stored_for)
+
+    def _stored_activations_valid(self, pol):
+        want = self._stored_for.get(pol)
+        if want is None or self._stored is None or self._stored.get(pol) is None:
+            return False
+        if want != parameter_versions(self.models[pol]):
+            if not getattr(self, "_warned_stale", False):
+                logging.warning(f"policy '{pol}': its parameters changed between the rollout and the update (outside the "
+                                "trainer's own optimizer step); the update recomputes its forward pass instead of reading "
+                                "the activations the rollout stored")
+                self._warned_stale = True
+            return False
+        return True
 
     # ---------------------------------------------------------------------------- update
     def _update_model_params(self, iteration, log):
@@ -459,17 +527,17 @@ class Trainer:
                 # the objective and its gradient with respect to the network's output as ONE kernel, the ReLU masks and
                 # bias gradients of the backward as one pass each (training/update_kernels.py), and for two 256-wide float32
                 # hidden layers the matrix products of the backward as well
-                stored = self._stored
-                if stored is not None and stored.get(pol) is not None and self._rollout_filled_stored:
+                if self._stored_activations_valid(pol):
                     # the forward pass is a read: the rollout's forward kernel stored these rows' activations and outputs
-                    out = self.models[pol].forward_logits_stored(batch["obs"][: self.batch_len], *stored[pol])
+                    out = self.models[pol].forward_logits_stored(batch["obs"][: self.batch_len], *self._stored[pol])
                 else:
                     with torch.autocast(device_type=self.device.type, dtype=self._update_dtype or torch.bfloat16,
                                         enabled=self._update_dtype is not None):
                         out = self.models[pol].forward_logits(batch["obs"][: self.batch_len])
                 loss, m = self.trainers[pol].compute_loss_and_metrics_from_logits(
                     self.current_timestep[pol], out.float(), batch["actions"][: self.batch_len],
-                    batch["rewards"][: self.batch_len], done[: self.batch_len], self.head_sizes, log)
+                    batch["rewards"][: self.batch_len], done[: self.batch_len], self.head_sizes, log,
+                    kernels=self._update_kernels)
                 torch.autograd.backward(loss, grad_tensors=update_kernels.unit_gradient(loss.device))  # = loss.backward()
                 if log:
                     metrics[pol] = m
@@ -487,7 +555,7 @@ class Trainer:
                 metrics[pol] = m
         # the stored activations belonged to the weights that are about to change: a second update on the same batch (or
         # anything else before the next rollout) recomputes its forward pass
-        self._rollout_filled_stored = False
+        self._stored_for = {}
         self.grad_bucket.all_reduce_mean()  # ONE collective for all policies (RCCL over xGMI at N > 1)
         for pol in trained:
             pcfg = self.config["policy"][pol]
@@ -569,7 +637,7 @@ class Trainer:
         for pol, path in ckpts_dict.items():
             assert os.path.isfile(path), f"invalid model checkpoint path {path}"
             models[pol].load_state_dict(torch.load(path, map_location=self.device))
-            self._rollout_filled_stored = False  # (activations stored by an earlier rollout belong to the old weights)
+            self._stored_for = {}  # (activations stored by an earlier rollout belong to the old weights)
             models[pol].refresh_inference_cache()
             stem = os.path.basename(path).split(".state_dict")[0]
             try:

@@ -22,21 +22,15 @@ framework's operations for the rest (profiles/r05_update_kernels.txt, r05_update
 "Bx3" = bf16x3 arithmetic: every float32 operand is split exactly into three bf16 terms and a product is the float32 sum
 of the six partial products that reach 2^-24 of it -- float32-accurate at 2.7 x the float32 matrix rate.
 
-`install(function_manager)` makes them available to training/models.py and training/losses.py; without it (CPU tests,
-other devices) both modules run their framework paths."""
+An `UpdateKernels` object belongs to ONE function manager (one device) and is handed around explicitly: the trainer
+stores it on each of its models (`FullyConnected.update_kernels`, from where it reaches the autograd nodes as an argument)
+and passes it to the objective (`compute_loss_and_metrics_from_logits(..., kernels=)`).  There is no process-wide switch: a
+trainer built with `fused_update: False`, or on another device, next to one that uses the kernels is unaffected; without a
+handle (CPU tests) both modules run their framework paths."""
+import logging
+
 import numpy as np
 import torch
-
-_ACTIVE = {"kernels": None}
-
-
-def active():
-    return _ACTIVE["kernels"]
-
-
-def install(function_manager):
-    _ACTIVE["kernels"] = UpdateKernels(function_manager) if function_manager is not None else None
-    return _ACTIVE["kernels"]
 
 
 class UpdateKernels:
@@ -44,10 +38,50 @@ class UpdateKernels:
     HEAD_WIDTHS = (43, 6, 3)  # output widths HipHeadBackward_W<w> exists for (21 + 21 + 1, 5 + 1, 2 + 1)
 
     def __init__(self, function_manager):
+        assert function_manager is not None
         names = ["HipPolicyGradientHead", "HipReluBackwardColumnSums"]
         function_manager.initialize_functions(names)
         self.head_fn, self.relu_fn = (function_manager.get_function(n) for n in names)
         self._fm, self._head_backward_fns = function_manager, {}
+
+    # ------------------------------------------------------------------------------------------------ what will run
+    def update_plan(self, model, rows, autocast=False):
+        """{step of the update: the kernel of this module that runs it, or "framework"} for one policy network and `rows`
+        batch rows -- decided by the same `supports_*` predicates the backward consults, on empty stand-in tensors.
+        The trainer logs this once at start: a shape the kernels do not cover falls back to the framework's GEMMs
+        step by step, and that is then on record rather than silent."""
+        dev = next(model.parameters()).device
+        W, widths = sum(model.head_sizes) + 1, [model.fc[str(i)][0].out_features for i in range(len(model.fc))]
+        obs = model.fc["0"][0].in_features if widths else model.vf_head.in_features
+        f32 = lambda *shape: _ShapeOnly(shape, dev)  # noqa: E731
+        plan = {"objective": "HipPolicyGradientHead" if self.supports_head(f32(rows, W), model.head_sizes) else "framework"}
+        if autocast or not widths:
+            plan["backward"] = "framework GEMMs" + (" + HipReluBackwardColumnSums" if widths and all(
+                self.supports_relu_backward(f32(rows, c), f32(rows, c)) for c in widths) else "")
+            return plan
+        C = widths[-1]
+        if self.supports_head_backward(f32(rows, W), f32(W, C), f32(rows, C)):
+            plan["output layer backward + mask + bias"] = (f"HipHeadBackwardBx3_W{W}" if C == 256 and rows >= self.WEIGHT_GRAD_MIN_ROWS
+                                                           else f"HipHeadBackward_W{W}")
+        else:
+            plan["output layer backward + mask + bias"] = "framework"
+        if len(widths) == 2:
+            plan["dW2"] = "HipWeightGradBx3_256x256" if self.supports_weight_grad(f32(rows, C), f32(rows, widths[0])) else "framework"
+            plan["input gradient of layer 2 + mask"] = (f"HipLinearMaskBackwardBx3_{C}" if self.supports_linear_mask_backward(
+                f32(rows, C), f32(C, C), f32(rows, widths[0])) and widths[0] == C else "framework")
+            plan["dW1 + db1"] = ("HipWeightGradBx3_256x96" if self.supports_weight_grad(f32(rows, widths[0]), f32(rows, obs), with_bias=True)
+                                 else "framework")
+        else:
+            plan["hidden layers below the last"] = "framework GEMMs + HipReluBackwardColumnSums"
+        return plan
+
+    @staticmethod
+    def log_update_plan(policy, plan):
+        fallen_back = [k for k, v in plan.items() if v.startswith("framework")]
+        logging.info(f"update of policy '{policy}': " + "; ".join(f"{k}: {v}" for k, v in plan.items()))
+        if fallen_back:
+            logging.warning(f"update of policy '{policy}': the network's shape is outside the hand-written kernels for "
+                            f"{', '.join(fallen_back)} -- those steps run as the framework's operations")
 
     # ------------------------------------------------------------------------------------------------ objective
     @staticmethod
@@ -257,8 +291,7 @@ class FusedObjective(torch.autograd.Function):
     out; `terms` (float64 [3], detached: policy loss, value loss, mean entropy) is returned beside it for the metrics."""
 
     @staticmethod
-    def forward(ctx, out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff, ppo):
-        k = active()
+    def forward(ctx, k, out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff, ppo):
         R = out.shape[0]
         grad, sums = k.policy_gradient_head(out, actions, adv, ret, head_sizes, ent_coeff, vf_coeff)
         policy_loss = -(sums[3] if ppo else sums[0]) / R  # PPO at ratio 1: min(ratio * A, clamp(ratio) * A) = A
@@ -273,8 +306,23 @@ class FusedObjective(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         if g_loss.data_ptr() == unit_gradient(grad.device).data_ptr():
             STATS["unit_gradient_hits"] += 1
-            return grad, None, None, None, None, None, None, None   # d loss / d loss = 1, known without reading it
-        return grad * g_loss.to(grad.dtype), None, None, None, None, None, None, None
+            return None, grad, None, None, None, None, None, None, None   # d loss / d loss = 1, known without reading it
+        return None, grad * g_loss.to(grad.dtype), None, None, None, None, None, None, None
+
+
+class _ShapeOnly:
+    """what the `supports_*` predicates read of a tensor (device, dtype, shape, contiguity), answered for a contiguous
+    float32 tensor of `shape` on `device` that is never allocated (a training batch's activations are gigabytes)"""
+
+    def __init__(self, shape, device):
+        self.device, self.dtype, self.shape = torch.device(device), torch.float32, torch.Size(shape)
+        self.is_cuda = self.device.type == "cuda"
+
+    def is_contiguous(self):
+        return True
+
+    def dim(self):
+        return len(self.shape)
 
 
 _UNIT = {}
