@@ -198,6 +198,13 @@ def main():
     ap.add_argument("--no-spread", action="store_true", help="skip the four extra repeats of the timed region")
     ap.add_argument("--profile-episodes", type=int, default=0,
                     help="profiler helper: run this many whole episodes of ticks and exit (no timing, no JSON)")
+    ap.add_argument("--trainer-leg", choices=("auto", "on", "off"), default="auto",
+                    help="add a `trainer` object to the line: ONE timed PPO training iteration of BASELINE configs[3] per rank "
+                         "(2000 replicas x 250 ticks, both policies, the real one-bucket gradient all-reduce) after one warm-up "
+                         "iteration -- rollout_ms, update_ms, allreduce_us measured inside the iteration, end-to-end env-steps/s, "
+                         "collectives per iteration, parameter checksum per rank.  auto = when --gpus > 1 (tag_continuous only)")
+    ap.add_argument("--trainer-num-envs", type=int, default=2000, help="replicas per rank of the trainer leg")
+    ap.add_argument("--trainer-ticks", type=int, default=250, help="ticks per training iteration of the trainer leg")
     ap.add_argument("--unfused", action="store_true",
                     help="tick = 4 launches (sample x2, step, fused reset) instead of the single tick kernel")
     args = ap.parse_args()
@@ -374,6 +381,23 @@ def main():
     kern_us = (sum(win_us) + sum(win_us2)) / (len(win_us) + len(win_us2))
     kern_n = (len(win_us) + len(win_us2)) * WIN
 
+    # BASELINE configs[3] is a TRAINING configuration (PPO + the gradient all-reduce over RCCL): at N > 1 the line also
+    # carries one training iteration timed from the inside, on every rank (collectives inside: all ranks take part)
+    trainer_leg = None
+    if is_tc and (args.trainer_leg == "on" or (args.trainer_leg == "auto" and world > 1)):
+        from warp_drive_amd.training.bench_iteration import run_configs3_iteration
+
+        try:
+            trainer_leg = run_configs3_iteration(args.trainer_num_envs, args.trainer_ticks, warmup_iterations=1)
+            trainer_leg["hardware_note"] = ("RCCL over xGMI" if world > 1 and os.environ.get("WD_DIST_BACKEND") in (None, "", "nccl")
+                                            else "single rank: no collective" if world == 1 else
+                                            f"backend {os.environ.get('WD_DIST_BACKEND')} (not RCCL)")
+        except Exception as err:  # the kernel line is the contract; a failed trainer leg must not lose it
+            import traceback
+
+            traceback.print_exc()
+            trainer_leg = {"failed": f"{type(err).__name__}: {err}"}
+
     if rank == 0:
         N = w.n_agents
         if args.workload == "tag_continuous":
@@ -487,6 +511,8 @@ def main():
             "roofline_valu": valu_roofline(engine.step_kernel_name, E, bool(args.full_obs), kern_us)
             if is_tc else None,
         }
+        if trainer_leg is not None:
+            out["trainer"] = trainer_leg
         if is_tc and args.mode == "plan" and kern_us > 0:
             # The cost of a TagContinuous tick falls along the episode (agents leave the game), so a `value` timed over a
             # window that is not a whole number of episodes is the rate of THAT window (the contract: exactly K timed

@@ -207,3 +207,102 @@ def test_valu_roofline_from_a_pmc_file(tmp_path, monkeypatch):
     assert bench.valu_roofline("HipTagContinuousTick_K10", 8000, False, 10.0) is None   # other shape
     hsaco.write_bytes(b"another code object")
     assert bench.valu_roofline("HipTagContinuousTick_K10", 2000, False, 10.0) is None   # other code object
+
+
+class _StandInTrainer:
+    """what `bench_iteration.measure_training_iteration` touches of a Trainer, on CPU: two policies (the networks of the
+    TagContinuous run, shrunk), the REAL one-bucket GradientBucket over the job's process group, a rollout that only costs
+    time and an update that differentiates a rank-dependent batch, averages the gradients with the bucket's one
+    collective and steps -- the N > 1 control flow of training/trainer.py::_update_model_params without a GPU"""
+
+    def __init__(self, rank, num_envs=6, ticks=5):
+        import torch
+
+        from warp_drive_amd.training.grad_bucket import GradientBucket
+        from warp_drive_amd.training.losses import PPO
+        from warp_drive_amd.training.models import FullyConnected
+
+        torch.manual_seed(100 + rank)   # ranks start from DIFFERENT weights: the bucket's broadcast must align them
+        self.device = torch.device("cpu")
+        self.models = {"runner": FullyConnected(9, [4, 3], (16, 16)), "tagger": FullyConnected(9, [4, 3], (16, 16))}
+        self.trainers = {p: PPO(clip_param=0.1) for p in self.models}
+        self.optimizers = {p: torch.optim.Adam(m.parameters(), lr=1e-2) for p, m in self.models.items()}
+        self.grad_bucket = GradientBucket(list(self.models.values()), self.device)
+        self.grad_bucket.broadcast_parameters(src=0)
+        self.num_envs, self.batch_len = num_envs, ticks
+        self.train_batch_size = num_envs * ticks
+        self.update_plan = {p: {"objective": "framework"} for p in self.models}
+        self.rank, self.rollouts = rank, 0
+        self.gen = torch.Generator().manual_seed(7 + rank)   # own replicas: own data
+
+    def _generate_rollout_batch(self):
+        self.rollouts += 1
+
+    def _update_model_params(self, iteration, log):
+        import torch
+
+        self.grad_bucket.zero()
+        for p, m in self.models.items():
+            x = torch.randn(self.batch_len, self.num_envs, 2, 9, generator=self.gen)
+            probs, values = m(x)
+            (sum(pr.log().mean() for pr in probs) + values.square().mean()).backward()
+        self.grad_bucket.all_reduce_mean()
+        for p in self.models:
+            self.optimizers[p].step()
+
+    def graceful_close(self):
+        pass
+
+
+def _iteration_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from warp_drive_amd import distributed as wdd
+    from warp_drive_amd.training.bench_iteration import measure_training_iteration
+
+    wdd.init_process_group(backend="gloo")
+    assert wdd.init_process_group(backend="gloo")[2] == world   # (a second call inside a live group is a no-op)
+    tr = _StandInTrainer(rank)
+    rec = measure_training_iteration(tr, warmup_iterations=1)
+    rec["rollouts"] = tr.rollouts
+    with open(os.path.join(out_dir, f"it_{rank}.json"), "w") as f:
+        json.dump(rec, f)
+    wdd.shutdown()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_trainer_object_of_the_bench_line_over_gloo(tmp_path, world):
+    """bench.py --gpus N's `trainer` object (BASELINE configs[3]: PPO + the gradient all-reduce), schema and invariants,
+    with world_size 2 and 8 over gloo: one warm-up + ONE timed iteration, exactly one collective in it -- timed inside the
+    update on the real bucket --, whole-job env-steps / the slowest rank's iteration time, and identical parameters on every
+    rank afterwards although the ranks started from different weights and saw different batches."""
+    mp.spawn(_iteration_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    recs = [json.load(open(tmp_path / f"it_{r}.json")) for r in range(world)]
+    keys = {"algorithm", "num_envs_per_rank", "ticks_per_iteration", "env_steps_per_iteration_all_ranks", "rollout_ms", "update_ms",
+            "iteration_ms", "env_steps_per_s_end_to_end", "allreduce_us", "allreduce_us_per_rank", "gradient_bucket_bytes",
+            "collectives_per_iteration", "parameter_checksum_per_rank", "parameters_identical_across_ranks", "update_plan",
+            "warmup_iterations", "rollouts"}
+    for r in recs:
+        assert set(r) == keys, set(r) ^ keys
+        assert r["algorithm"] == ["PPO"] and r["collectives_per_iteration"] == 1 and r["rollouts"] == 2
+        assert r["env_steps_per_iteration_all_ranks"] == world * 30
+        assert r["parameters_identical_across_ranks"] and len(set(r["parameter_checksum_per_rank"])) == 1
+        assert len(r["allreduce_us_per_rank"]) == world and all(v > 0 for v in r["allreduce_us_per_rank"])
+        assert r["allreduce_us"] == max(r["allreduce_us_per_rank"])
+        assert r["iteration_ms"] >= max(r["rollout_ms"], r["update_ms"]) > 0
+        assert abs(r["env_steps_per_s_end_to_end"] - world * 30 / (r["iteration_ms"] * 1e-3)) < 1e-6 * r["env_steps_per_s_end_to_end"]
+        assert r["gradient_bucket_bytes"] == 4 * 2 * sum(p.numel() for p in _StandInTrainer(0).models["runner"].parameters())
+    # every rank reports the same (reduced) record
+    for k in keys - {"rollouts"}:
+        assert all(r[k] == recs[0][k] for r in recs), k
+
+
+def test_configs3_overrides_are_what_baseline_names():
+    """the trainer leg's configuration = BASELINE configs[3] per rank: 2000 replicas, 250 ticks, PPO for both policies"""
+    from warp_drive_amd.training import bench_iteration as bi
+
+    ov = bi.configs3_overrides()
+    assert ov["trainer"]["num_envs"] == 2000 and ov["trainer"]["train_batch_size"] == 500000
+    import inspect
+
+    src = inspect.getsource(bi.run_configs3_iteration)
+    assert 'algorithm="PPO"' in src and '"tag_continuous"' in src

@@ -38,14 +38,15 @@ _CARTPOLE = {"trainer": {"num_envs": 1000, "train_batch_size": 1000 * 50, "num_e
 def test_cartpole_learns(path, tmp_path):
     """Cartpole pays 1 per tick: "Mean episodic reward" is the mean episode length (~19-22 ticks under the random initial
     policy, 200 at most here).  A2C on the [32, 32] policy of run_configs/single_cartpole.yaml must at least TRIPLE it
-    within 200 iterations of 50 ticks x 1000 replicas -- with the policy evaluated inside the env's rollout kernel (one
+    within 300 iterations of 50 ticks x 1000 replicas (seeds 0-3 of
+    scripts/learning_curves.py reach 4-7 x after 200) -- with the policy evaluated inside the env's rollout kernel (one
     launch per batch) and on the per-tick path (framework forward -> fused tick kernel), replayed from a hipGraph and
     eager."""
     ov = json.loads(json.dumps(_CARTPOLE))
     if path != "one launch per batch":
         ov["trainer"]["fused_rollout_policy"] = False
         ov["trainer"]["graph_rollout"] = path == "per tick (hipGraph)"
-    tr, curve = _curve("single_cartpole", ov, "shared", 200, tmp_path)
+    tr, curve = _curve("single_cartpole", ov, "shared", 300, tmp_path)
     assert (tr._batch_rollout is not None) == (path == "one launch per batch")
     assert (tr._tick_graph is not None) == (path == "per tick (hipGraph)")
     first, last = float(np.mean(curve[:3])), float(np.mean(curve[-10:]))
@@ -54,21 +55,25 @@ def test_cartpole_learns(path, tmp_path):
     assert last >= 3.0 * first, (first, last, curve[::10])
 
 
-@pytest.mark.parametrize("fc_dims,lr,path", [([32, 32], 0.005, "one launch per batch"), ([256, 256], 0.002, "per tick")])
-def test_gridworld_taggers_learn_to_catch_a_random_runner(fc_dims, lr, path, tmp_path):
-    """TagGridWorld 10 x 10, 4 taggers + 1 runner (run_configs/tag_gridworld.yaml): the taggers earn 10 for a tag and pay
-    0.01 per tick.  With the runner kept at its random initial policy (`to_train: False`) the taggers' "Mean episodic
-    reward" after 60 iterations of 100 ticks x 600 replicas must exceed the first iterations' by 1.5 -- both with the
-    [32, 32] networks evaluated inside the rollout kernel and with the [256, 256] networks on the per-tick path (fused
-    forward kernel, matrix-core update)."""
+@pytest.mark.parametrize("fc_dims,path", [([32, 32], "one launch per batch"), ([256, 256], "per tick")])
+def test_gridworld_taggers_learn_to_catch_a_random_runner(fc_dims, path, tmp_path):
+    """TagGridWorld, 4 taggers + 1 runner on a 20 x 20 grid (run_configs/tag_gridworld.yaml's rewards: the taggers earn 10
+    for a tag and pay 0.01 per tick; random taggers rarely find a random runner on a grid this size within 100 ticks:
+    "Mean episodic reward" starts near 0).  With the runner kept at its random initial policy (`to_train: False`) the
+    taggers' reward over the last 10 of 60 iterations of 100 ticks x 600 replicas must exceed the first iterations' by 3
+    (measured: -0.3 -> 6.2 and 1.1 -> 7.0) -- with the [32, 32] networks evaluated inside the rollout kernel and with the
+    [256, 256] networks on the per-tick path (fused forward kernel; the update's matrix-core kernels below their row
+    threshold, i.e. partly framework GEMMs -- the plan logged at start says which)."""
+    lr = 0.001
     pol = {p: {"to_train": p == "tagger", "algorithm": "A2C", "vf_loss_coeff": 1, "entropy_coeff": 0.05, "gamma": 0.98, "lr": lr,
                "model": {"type": "fully_connected", "fc_dims": fc_dims, "model_ckpt_filepath": ""}} for p in ("runner", "tagger")}
-    ov = {"trainer": {"num_envs": 600, "train_batch_size": 600 * 100, "num_episodes": 10 ** 6, "seed": 7}, "policy": pol}
+    ov = {"trainer": {"num_envs": 600, "train_batch_size": 600 * 100, "num_episodes": 10 ** 6, "seed": 7}, "policy": pol,
+          "env": {"grid_length": 20}}
     tr, curve = _curve("tag_gridworld", ov, "tagger", 60, tmp_path)
     assert (tr._batch_rollout is not None) == (path == "one launch per batch")
     first, last = float(np.mean(curve[:3])), float(np.mean(curve[-10:]))
     print(f"gridworld taggers, {path}: mean episodic reward {first:.2f} -> {last:.2f}")
-    assert last >= first + 1.5, (first, last, curve[::5])
+    assert last >= first + 3.0, (first, last, curve[::5])
 
 
 @pytest.mark.parametrize("graph", [True, False])

@@ -51,6 +51,32 @@ def test_bench_two_ranks_started_plainly():
     assert two["roofline"]["samples"] > 0 and two["roofline"]["achieved"] > 0
 
 
+def test_bench_line_carries_the_configs3_trainer_iteration():
+    """`bench.py --gpus 2` (and `--trainer-leg on` at N = 1): the line carries a `trainer` object -- ONE timed PPO training
+    iteration per rank after a warm-up, at a small size here -- with exactly one collective per iteration at N = 2, timed
+    inside the update on the real bucket (762 200 bytes: both [256, 256] policies), identical parameters on both ranks, and
+    end-to-end env-steps/s = all ranks' steps / the slowest rank's iteration.  (Two ranks on ONE device over gloo: the
+    control flow of configs[3], not its speed.)"""
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    small = ["--trainer-num-envs", "60", "--trainer-ticks", "12"]
+    one = _bench(["--trainer-leg", "on"] + small)["trainer"]
+    assert "failed" not in one, one
+    assert one["algorithm"] == ["PPO"] and one["collectives_per_iteration"] == 0 and one["allreduce_us"] is None
+    assert one["env_steps_per_iteration_all_ranks"] == 60 * 12 and one["gradient_bucket_bytes"] == 762200
+    two = _bench(["--gpus", "2"] + small)   # auto: on at N > 1
+    t = two["trainer"]
+    assert "failed" not in t, t
+    assert t["collectives_per_iteration"] == 1 and t["allreduce_us"] > 0 and len(t["allreduce_us_per_rank"]) == 2
+    assert t["parameters_identical_across_ranks"] and len(set(t["parameter_checksum_per_rank"])) == 1
+    assert t["env_steps_per_iteration_all_ranks"] == 2 * 60 * 12 and t["num_envs_per_rank"] == 60
+    assert abs(t["env_steps_per_s_end_to_end"] - 2 * 60 * 12 / (t["iteration_ms"] * 1e-3)) < 1e-6 * t["env_steps_per_s_end_to_end"]
+    assert t["iteration_ms"] >= max(t["rollout_ms"], t["update_ms"]) > 0
+    assert "gloo" in t["hardware_note"]
+    assert set(t["update_plan"]) == {"runner", "tagger"}
+
+
 def test_train_two_ranks(tmp_path):
     from tests.hip_harness import require_gpu
 

@@ -206,12 +206,13 @@ def test_stale_stored_activations_are_not_differentiated(tmp_path):
     trainers = {}
     for reuse in (True, False):
         ov = {"trainer": {"num_envs": 29, "train_batch_size": 29 * 10, "num_episodes": 4000, "seed": 3,
-                          "reuse_rollout_activations": reuse},
+                          "reuse_rollout_activations": reuse, "fused_policy_forward_min_rows": 0},
               "env": {"num_runners": 40, "episode_length": 8, "num_other_agents_observed": 10},
               "saving": {"metrics_log_freq": 1, "model_params_save_freq": 0}}
         torch.manual_seed(0)
         trainers[reuse] = setup_trainer("tag_continuous", ov, results_dir=str(tmp_path / f"s{int(reuse)}"), verbose=False)
     a, b = trainers[True], trainers[False]
+    assert a._stored is not None and a._fast_tick is not None and b._stored is None
     for tr in (a, b):
         tr._generate_rollout_batch()
     assert all(a._stored_activations_valid(pol) for pol in a.policies)

@@ -93,7 +93,7 @@ def pin_rank_to_cpus(local_rank=None, local_world=None, device=None):
 
 def init_process_group(backend=None, device_id=None):
     rank, local_rank, world = rank_info()
-    if world == 1:
+    if world == 1 or (dist.is_available() and dist.is_initialized()):  # (bench.py builds a trainer inside its own group)
         return rank, local_rank, world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")

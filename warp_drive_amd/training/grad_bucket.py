@@ -23,6 +23,10 @@ class GradientBucket:
             p.grad = self.flat[offset: offset + p.numel()].view_as(p)  # autograd accumulates into the view in place
             offset += p.numel()
         self.collectives = 0  # all-reduces issued so far (tests / metrics)
+        # bench.py's `trainer` object: time the collective where it happens (events on the stream it is enqueued on for
+        # RCCL, wall clock for gloo); off by default -- the events cost nothing but are nobody's business otherwise
+        self.time_collectives = False
+        self._timed = None
         self.reattached = 0   # times a detached .grad had to be put back into the bucket (see _reattach)
 
     @staticmethod
@@ -62,9 +66,32 @@ class GradientBucket:
         self._reattach()
         if not self._group_active():
             return
-        dist.all_reduce(self.flat)
+        if not self.time_collectives:
+            dist.all_reduce(self.flat)
+        elif self.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(self.flat)
+            e1.record()
+            self._timed = (e0, e1)
+        else:
+            import time
+
+            t0 = time.perf_counter()
+            dist.all_reduce(self.flat)
+            self._timed = (time.perf_counter() - t0) * 1e6
         self.flat.div_(dist.get_world_size())
         self.collectives += 1
+
+    def read_allreduce_us(self):
+        """duration (us) of the last all-reduce issued while `time_collectives` was set, or None"""
+        if self._timed is None:
+            return None
+        if isinstance(self._timed, tuple):
+            e0, e1 = self._timed
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3
+        return float(self._timed)
 
     @torch.no_grad()
     def broadcast_parameters(self, src=0):
