@@ -20,7 +20,10 @@ rounds, names = int(args[0]), args[1:]
 res = {n: [] for n in names}
 for _ in range(rounds):
     for n in names:
-        env = dict(os.environ, WD_HSACO_DIR=os.path.join(ROOT, "build", "variants", n))
+        vdir = os.path.join(ROOT, "build", "variants", n)
+        env = dict(os.environ, WD_HSACO_DIR=vdir)
+        if os.path.exists(os.path.join(vdir, "env")):  # KEY=VALUE lines: host-side switches that belong to the variant
+            env.update(dict(line.strip().split("=", 1) for line in open(os.path.join(vdir, "env")) if "=" in line))
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1000", "--warmup", "100",
                               "--no-cpu-baseline", "--no-spread"] + extra, capture_output=True, text=True, env=env)
         try:
