@@ -668,3 +668,4 @@ def test_integration_md_stub_verbatim():
     assert t >= 4 and orc.done.any(), t
     for d in (x, y, act, done, tstep, rew, obs):
         check(lib.wd_free(d.ptr), "free")
+

@@ -127,7 +127,28 @@ struct CpResetEntry {  // same layout as wd_reset_entry in wd_core.hip
 // one launch (the reference runs policy forward, sampler, step and reset as separate launches with
 // three host synchronisations per tick, trainer_base.py:392-426).
 // (No __restrict__ on the arrays: the reset table aliases them.)
-template <int H>
+// stores of the tick loop through a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: the per-lane 64-bit
+// address arithmetic of four record arrays per tick (a v_mad_u64 and three-instruction adds each) becomes scalar work.
+// Untracked like wd_store_untracked (wd_common.h): the loop never reads these addresses back.
+__device__ __forceinline__ void cp_store_s(const void *sbase, uint32_t voff, int v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void cp_store_s(const void *sbase, uint32_t voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void cp_store_s(const void *sbase, uint32_t voff, float4 v) {
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  const v4f_ q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q), "s"(sbase) : "memory");
+}
+
+// BATCH: the four `*_batch` pointers are given (every tick recorded) -- a compile-time copy of the loop for each case, so
+// that the tick carries no "is there a batch" branches
+struct CpTrue { static constexpr bool value = true; };
+struct CpFalse { static constexpr bool value = false; };
+
+// A2: exactly two actions (Cartpole's own action space), known at compile time
+template <int H, bool BATCH, bool A2 = false>
 __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
     float4 *state_arr, int *action_arr, int *done_arr,
     float *reward_arr, float4 *observation_arr, float gravity,
@@ -189,13 +210,35 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
     asm volatile("" : "+v"(row0.x), "+v"(row0.y), "+v"(row0.z), "+v"(row0.w), "+v"(row1.x), "+v"(row1.y), "+v"(row1.z), "+v"(row1.w));
 #pragma unroll
     for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) asm volatile("" : "+v"(cumv[i]));
-    for (int k = 0; k < ticks; ++k) {
+    // per-lane byte offsets of this replica's row in the 16-byte and the 4-byte arrays (constant over the ticks); the
+    // record arrays' row k starts n_envs elements further on every tick: a scalar pointer
+    const uint32_t off16 = 16u * (uint32_t)env, off4 = 4u * (uint32_t)env;
+    const unsigned char *ob_k = (const unsigned char *)obs_batch, *ab_k = (const unsigned char *)action_batch,
+                        *rb_k = (const unsigned char *)reward_batch, *db_k = (const unsigned char *)done_batch;
+    // a batch launch whose restore rows sit in registers keeps the per-tick arrays, the state and the restored rows in
+    // registers until the LAST tick: every one of those addresses is written again then (the per-tick arrays and the
+    // state on the last tick of every replica, the registered rows = state + observation), so what memory holds after
+    // the launch is the same, and a replica that finishes mid-launch costs two register moves instead of seven stores
+    // (`cached` is the same in every lane -- the table is one per launch -- but it was computed from vector loads: say so,
+    // or the two loops below become divergent control flow and the record pointers vector registers)
+    const bool lazy = BATCH && (__builtin_amdgcn_readfirstlane(cached ? 1 : 0) != 0);
+    // the state a finished replica restarts from (the preloaded row registered for `state`)
+    const uint4 sr0 = ((size_t)ent0.data == (size_t)state_arr) ? row0 : row1;
+    const float4 s_restart = make_float4(__uint_as_float(sr0.x), __uint_as_float(sr0.y), __uint_as_float(sr0.z), __uint_as_float(sr0.w));
+
+    // ---- one tick.  MID (compile time): a tick of a `lazy` launch that is not its last -- four record stores, the Euler
+    // step, and a finished replica restarts by five selects: no per-tick-array stores, no branch on "finished", no
+    // divergent code at all.  Otherwise the general tick (`last` = the launch's last tick).
+    auto tick = [&](int k, auto mid_tag, bool last) __attribute__((always_inline)) {
+      constexpr bool MID = decltype(mid_tag)::value;
       // ---- sample (random.cu:51-85): inverse CDF on a running float32 sum
       const float u = wd_u01_open_closed(wd_tick_draw((uint32_t)env, epoch0 + (uint32_t)k, (uint32_t)stream_tag, k0, k1,
                                                       blk, blk_quad));
       if (H > 0) cp_policy_cum<(H > 0 ? H : 4)>(cp_weights, s, n_actions, cumv);  // live policy: THIS tick's observation
       int cnt = 0;
-      if (n_actions <= CP_MAX_REG_ACTIONS) {
+      if (A2 || n_actions == 2) {  // (uniform) two compares instead of eight masked ones
+        cnt = ((cumv[0] < u) ? 1 : 0) + ((cumv[1] < u) ? 1 : 0);
+      } else if (n_actions <= CP_MAX_REG_ACTIONS) {
 #pragma unroll
         for (int i = 0; i < CP_MAX_REG_ACTIONS; ++i) cnt += (i < n_actions && cumv[i] < u) ? 1 : 0;
       } else {
@@ -205,38 +248,45 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
           cnt += (cum < u) ? 1 : 0;
         }
       }
-      const int a = min(cnt, n_actions - 1);
+      const int a = min(cnt, (A2 ? 2 : n_actions) - 1);
       // ---- step
-      const long brow = (long)k * n_envs + env;
-      if (obs_batch) wd_store_untracked(obs_batch + brow, s);  // the observation this action was sampled on
+      if (BATCH) cp_store_s(ob_k, off16, s);  // the observation this action was sampled on
       t += 1;
       const bool terminated = cp_euler(s, a, p);
       const bool fin = (t == episode_length) || terminated;
-      if (obs_batch) {
-        wd_store_untracked(action_batch + brow, a);
-        wd_store_untracked(reward_batch + brow, 1.0f);
-        wd_store_untracked(done_batch + brow, fin ? 1 : 0);
+      if (BATCH) {
+        cp_store_s(ab_k, off4, a);
+        cp_store_s(rb_k, off4, 1.0f);
+        cp_store_s(db_k, off4, fin ? 1 : 0);
+        ob_k += 16 * (size_t)n_envs; ab_k += 4 * (size_t)n_envs; rb_k += 4 * (size_t)n_envs; db_k += 4 * (size_t)n_envs;
+      }
+      if (MID) {
+        t = fin ? 0 : t;
+        s.x = fin ? s_restart.x : s.x; s.y = fin ? s_restart.y : s.y;
+        s.z = fin ? s_restart.z : s.z; s.w = fin ? s_restart.w : s.w;
+        return;
       }
       // (untracked stores, wd_common.h: a store the compiler tracks inside the loop costs a wait for ALL stores on
       // every trip, executed or not.  The one place that reads such an address back -- the restore of a replica whose
       // reset rows were not preloaded -- drains the counter itself first.)
-      if (!obs_batch || k == ticks - 1 || fin) {
-        wd_store_untracked(action_arr + env, a);
-        wd_store_untracked(observation_arr + env, s);
-        wd_store_untracked(reward_arr + env, 1.0f);
-        wd_store_untracked(done_arr + env, fin ? 1 : 0);
+      if (!BATCH || last || (fin && !lazy)) {
+        cp_store_s(action_arr, off4, a);
+        cp_store_s(observation_arr, off16, s);
+        cp_store_s(reward_arr, off4, 1.0f);
+        cp_store_s(done_arr, off4, fin ? 1 : 0);
       }
-      if (fin || k == ticks - 1) wd_store_untracked(state_arr + env, s);  // otherwise the state stays in registers
+      if (last || (fin && !lazy)) cp_store_s(state_arr, off16, s);  // otherwise the state stays in registers
       // ---- reset in place (reset.cu:9-75 for every registered array); `_done_` stays set
       if (fin) {
         t = 0;
         if (cached) {  // stores only
-          // (after the untracked stores above to the same rows: stores of one wavefront to one address stay in order)
-          wd_store_untracked((float4 *)ent0.data + env, make_float4(__uint_as_float(row0.x), __uint_as_float(row0.y), __uint_as_float(row0.z), __uint_as_float(row0.w)));
-          if (n_reset_arrays == 2)
-            wd_store_untracked((float4 *)ent1.data + env, make_float4(__uint_as_float(row1.x), __uint_as_float(row1.y), __uint_as_float(row1.z), __uint_as_float(row1.w)));
-          const uint4 sr = ((size_t)ent0.data == (size_t)state_arr) ? row0 : row1;
-          s = make_float4(__uint_as_float(sr.x), __uint_as_float(sr.y), __uint_as_float(sr.z), __uint_as_float(sr.w));
+          if (last || !lazy) {
+            // (after the untracked stores above to the same rows: stores of one wavefront to one address stay in order)
+            wd_store_untracked((float4 *)ent0.data + env, make_float4(__uint_as_float(row0.x), __uint_as_float(row0.y), __uint_as_float(row0.z), __uint_as_float(row0.w)));
+            if (n_reset_arrays == 2)
+              wd_store_untracked((float4 *)ent1.data + env, make_float4(__uint_as_float(row1.x), __uint_as_float(row1.y), __uint_as_float(row1.z), __uint_as_float(row1.w)));
+          }
+          s = s_restart;
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the untracked stores above have left
           for (int r = 0; r < n_reset_arrays; ++r) {
@@ -250,6 +300,12 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
           asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w));
         }
       }
+    };
+    if (lazy) {  // (uniform) every tick but the last: the branch-free body
+      for (int k = 0; k < ticks - 1; ++k) tick(k, CpTrue{}, false);
+      tick(ticks - 1, CpFalse{}, true);
+    } else {
+      for (int k = 0; k < ticks; ++k) tick(k, CpFalse{}, k == ticks - 1);
     }
     env_timestep_arr[env] = t;
     rng_state[WD_RNG_HEADER + env] = epoch0 + (uint32_t)ticks;
@@ -289,7 +345,12 @@ __global__ void HipClassicControlCartPoleEnvTick(
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
     int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
     const float *policy, int hidden) {
-  cp_tick_impl<0>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+  if (obs_batch && n_actions == 2)  // the recorded two-action rollout (configs[4]): sizes folded
+    cp_tick_impl<0, true, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+  else if (obs_batch)
+    cp_tick_impl<0, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+  else
+    cp_tick_impl<0, false>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
 }
 
 // the rollout with a live policy (weights in dynamic LDS); `hidden` must equal the entry's width
@@ -304,7 +365,10 @@ __global__ void HipClassicControlCartPoleEnvTick(
     int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch, \
     const float *policy, int hidden) {           \
     extern __shared__ __attribute__((aligned(16))) float cp_lds[];                                 \
-    cp_tick_impl<HH>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);                                                \
+    if (obs_batch)                                                                                 \
+      cp_tick_impl<HH, true>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden); \
+    else                                                                                           \
+      cp_tick_impl<HH, false>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden); \
   }
 WD_CP_ROLLOUT(32)
 WD_CP_ROLLOUT(64)

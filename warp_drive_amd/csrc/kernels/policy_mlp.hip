@@ -471,7 +471,7 @@ __device__ __forceinline__ void mlp_store_activations(float *dst, const mlp_v16 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const mlp_v4 v = {acc[tn][4 * q], acc[tn][4 * q + 1], acc[tn][4 * q + 2], acc[tn][4 * q + 3]};
-      *(mlp_v4 *)(dst + 32 * tn + 8 * q + 4 * h) = v;
+      *(mlp_v4 *)(dst + 32 * tn + 8 * q + 4 * h) = v;   // (non-temporal stores here: no difference, docs/rounds/r06.md)
     }
 }
 

@@ -1,0 +1,784 @@
+// tc_knn.h -- K nearest neighbours of the fast path: one-pass packed-key chain, exact tie resolution, prefiltered search of big replicas, fallbacks.
+// Part of the TagContinuous translation unit (tag_continuous.hip, which holds the design notes, the probe macros
+// and the kernel entries); split by phase in round 6 with every shipped code object byte-identical before / after.
+#pragma once
+#include "wd_common.h"
+#include "tc_types.h"
+
+namespace {
+
+// =====================================================================================
+//                   fast path: N <= 512, partial observations, K <= KMAX
+// =====================================================================================
+
+struct TcP4 {
+  float2 p[4];
+};
+// positions of candidates j .. j+3 (j even; every replica's positions start 16-byte aligned): two
+// ds_read_b128 with a wave-uniform address -- half the LDS cycles of four 8-byte reads, and the LDS
+// pipe is what bounds pass B otherwise
+__device__ __forceinline__ TcP4 tc_load4(const float2 *cxy, int j) {
+  // (j is a multiple of 4 and every replica's positions start 16-byte aligned: say so, or a start index the compiler
+  // cannot see through turns the two ds_read_b128 into eight ds_read_b32)
+  const float4 *const q = (const float4 *)__builtin_assume_aligned(cxy + j, 16);
+  const float4 a = q[0], b = q[1];
+  TcP4 r;
+  r.p[0] = make_float2(a.x, a.y); r.p[1] = make_float2(a.z, a.w);
+  r.p[2] = make_float2(b.x, b.y); r.p[3] = make_float2(b.z, b.w);
+  return r;
+}
+
+// rank of entry k in the reference's order (distance, then id): the entries are in ascending id
+// order already, so entry j > i goes first only when it is STRICTLY closer.  Counting (one compare
+// and two carry adds per pair) instead of a compare-exchange network: a 64-bit compare-exchange is
+// a compare plus four v_cndmask, the slowest instruction class on gfx950 when they come in runs.
+template <int KMAX>
+__device__ __forceinline__ void tc_rank_entries(const unsigned (&sb)[KMAX], int (&rank)[KMAX]) {
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+    for (int j = i + 1; j < KMAX; ++j) {
+      const int c = (sb[j] < sb[i]) ? 1 : 0;
+      rank[i] += c;
+      rank[j] -= c;
+    }
+}
+
+template <int KMAX>
+__device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX],
+                                                 int (&rank)[KMAX]) {
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
+  const float INF = __builtin_inff();
+  // candidates are streamed four at a time, the next four positions being read from LDS while the
+  // current four are processed (the search is latency-bound otherwise: one LDS round trip per group)
+
+  // A. K+1 smallest squared distances over ALL agents of the replica (self contributes 0,
+  //    agents out of the game contribute +inf): B[k] = med3(B[k-1], B[k], d2), one op per slot,
+  //    no compares, no ids
+  float B[KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k) B[k] = INF;
+#define WD_TC_INSERT(d2v)                                                                         \
+  do {                                                                                            \
+    _Pragma("unroll") for (int k = KMAX; k >= 1; --k) B[k] = __builtin_amdgcn_fmed3f(B[k - 1], B[k], (d2v)); \
+    B[0] = fminf(B[0], (d2v));                                                                    \
+  } while (0)
+  {
+    const int ng = N >> 2;
+    TcP4 nxt = tc_load4(cxy, 0);
+    for (int g = 0; g < ng; ++g) {
+      const TcP4 cur = nxt;
+      nxt = tc_load4(cxy, 4 * g + 4);  // (the last prefetch lands in the padding behind the replica's positions)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = xi - cur.p[u].x, dy = yi - cur.p[u].y;
+        const float d2 = dx * dx + dy * dy;
+        WD_TC_INSERT(d2);
+      }
+    }
+    for (int j = 4 * ng; j < N; ++j) {
+      const float2 pj = cxy[j];
+      const float dx = xi - pj.x, dy = yi - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      WD_TC_INSERT(d2);
+    }
+  }
+#undef WD_TC_INSERT
+  __builtin_amdgcn_s_setprio(1);
+  // B[k], k = 1..K are the K smallest squared distances to OTHER agents (B[0] is self or a
+  // co-located twin).  T2 = the K-th of them.
+  float T2 = INF;
+#pragma unroll
+  for (int k = 1; k <= KMAX; ++k) T2 = (k == K) ? B[k] : T2;
+  // The reference orders by float32 sqrt distance and breaks ties by id (heapq.nsmallest is stable,
+  // :435-437).  sqrt rounds, so a RANGE [T2lo, T2hi] of squared distances maps to the K-th distance
+  // S = sqrtf(T2); it is derived exactly in float64 from the midpoints around S.
+  float T2lo, T2hi;
+  if (T2 == INF) {          // fewer than K candidates in the game: take them all
+    T2lo = INF; T2hi = 3.0e38f;
+  } else if (T2 == 0.0f) {  // K twins at distance 0
+    T2lo = 0.0f; T2hi = 0.0f;
+  } else {
+    const float S = sqrtf(T2);
+    const float Sup = __uint_as_float(__float_as_uint(S) + 1u), Sdn = __uint_as_float(__float_as_uint(S) - 1u);
+    const double mhi = 0.5 * ((double)S + (double)Sup), mlo = 0.5 * ((double)S + (double)Sdn);
+    // sqrtf(x) == S  <=>  mlo^2 < x < mhi^2  (midpoints squared are exact in float64 and are
+    // never float32 values themselves)
+    const double hi2 = mhi * mhi, lo2 = mlo * mlo;
+    float th = (float)hi2, tl = (float)lo2;  // round to nearest, then step to the inside
+    if ((double)th > hi2) th = __uint_as_float(__float_as_uint(th) - 1u);
+    if ((double)tl < lo2) tl = __uint_as_float(__float_as_uint(tl) + 1u);
+    T2hi = th;
+    T2lo = tl;
+  }
+  // B. second pass: one 128-bit per-lane mask "inside or below the range".  Each candidate costs
+  //    a squared distance, one compare and one shift-in-the-carry add (m = 2m + bit); no
+  //    data-dependent addressing.  Candidate b of word w lands on bit (nb-1-b): undone with one
+  //    bit-reverse per word.
+  unsigned sel[4] = {0u, 0u, 0u, 0u};
+  int n_upto = 0;
+#define WD_TC_PUSH(m, d2v, thr, op) \
+  asm("v_cmp_" op "_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(thr) : "vcc")
+  {
+#define WD_TC_PUSH4(m, g)                                                       \
+  do {                                                                          \
+    float d_[4];                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                             \
+      const float dx = xi - (g).p[u].x, dy = yi - (g).p[u].y;                   \
+      d_[u] = dx * dx + dy * dy;                                                \
+    }                                                                           \
+    WD_TC_PUSH(m, d_[0], T2hi, "le"); WD_TC_PUSH(m, d_[1], T2hi, "le");         \
+    WD_TC_PUSH(m, d_[2], T2hi, "le"); WD_TC_PUSH(m, d_[3], T2hi, "le");         \
+  } while (0)
+    int w_first = 0;  // words already done by the interleaved loop below
+    if (N >= 96) {
+      // three full words at once: three INDEPENDENT compare / carry chains interleaved, so that one
+      // chain's carry latency is covered by the other two (a single chain issues a dependent pair
+      // per candidate)
+      unsigned m3[3] = {0u, 0u, 0u};
+#define WD_TC_PUSH12(g0, g1, g2)                                                  \
+  do {                                                                            \
+    float e_[3][4];                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                               \
+      const float ax = xi - (g0).p[u].x, ay = yi - (g0).p[u].y;                   \
+      const float bx = xi - (g1).p[u].x, by = yi - (g1).p[u].y;                   \
+      const float cx = xi - (g2).p[u].x, cy = yi - (g2).p[u].y;                   \
+      e_[0][u] = ax * ax + ay * ay; e_[1][u] = bx * bx + by * by; e_[2][u] = cx * cx + cy * cy; \
+    }                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                               \
+      WD_TC_PUSH(m3[0], e_[0][u], T2hi, "le");                                    \
+      WD_TC_PUSH(m3[1], e_[1][u], T2hi, "le");                                    \
+      WD_TC_PUSH(m3[2], e_[2][u], T2hi, "le");                                    \
+    }                                                                             \
+  } while (0)
+      TcP4 a0 = tc_load4(cxy, 0), a1 = tc_load4(cxy, 32), a2 = tc_load4(cxy, 64), b0, b1, b2;
+      for (int b = 0; b < 32; b += 8) {
+        b0 = tc_load4(cxy, b + 4); b1 = tc_load4(cxy, b + 36); b2 = tc_load4(cxy, b + 68);
+        WD_TC_PUSH12(a0, a1, a2);
+        a0 = tc_load4(cxy, b + 8); a1 = tc_load4(cxy, b + 40); a2 = tc_load4(cxy, b + 72);
+        WD_TC_PUSH12(b0, b1, b2);
+      }
+#undef WD_TC_PUSH12
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
+        sel[w] = __brev(m3[w]) & ~self_bit;
+        n_upto += __popc(sel[w]);
+      }
+      w_first = 3;
+    }
+    TcP4 ga = tc_load4(cxy, 32 * w_first), gb;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = 32 * w;
+      if (w >= w_first && j0 < N) {  // wave-uniform
+        const int nb = min(32, N - j0);
+        unsigned mu = 0u;
+        int b = 0;
+        // two groups of four per trip, ping-pong: the loads of one group are in flight while the
+        // other is processed, and no register is copied
+        for (; b + 8 <= nb; b += 8) {
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_PUSH4(mu, ga);
+          ga = tc_load4(cxy, j0 + b + 8);  // (at most 8 entries past the last candidate: padding)
+          WD_TC_PUSH4(mu, gb);
+        }
+        if (b + 4 <= nb) {
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_PUSH4(mu, ga);
+          ga = gb;
+          b += 4;
+        }
+        for (; b < nb; ++b) {  // (only the last word can have a remainder)
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
+          const float d2 = dx * dx + dy * dy;
+          WD_TC_PUSH(mu, d2, T2hi, "le");
+        }
+        const unsigned self_bit = ((ag >> 5) == w) ? (1u << (ag & 31)) : 0u;
+        sel[w] = (__brev(mu) >> (32 - nb)) & ~self_bit;
+        n_upto += __popc(sel[w]);
+      }
+    }
+#undef WD_TC_PUSH4
+  }
+  // Usually exactly K others are inside or below the range and the mask is the answer.  More
+  // than K means several candidates share the K-th float32 distance: the reference keeps the
+  // lowest ids among them.  Rare (a float32 sqrt tie at the cut), so the "strictly below" mask is
+  // only built then.
+  if (n_upto > K) {
+    unsigned lo[4] = {0u, 0u, 0u, 0u};
+    int c_less = 0;  // others strictly below the range
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = 32 * w;
+      if (j0 < N) {
+        const int nb = min(32, N - j0);
+        unsigned mb = 0u;
+        for (int b = 0; b < nb; ++b) {
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
+          const float d2 = dx * dx + dy * dy;
+          WD_TC_PUSH(mb, d2, T2lo, "lt");
+        }
+        lo[w] = (__brev(mb) >> (32 - nb)) & sel[w];
+        c_less += __popc(lo[w]);
+      }
+    }
+    int quota = K - c_less;  // members of the range still to take, ascending id
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned tie = sel[w] & ~lo[w];
+      const int have_t = __popc(tie);
+      if (have_t > quota) {  // keep the lowest `quota` set bits
+        unsigned kept = 0u;
+        for (int q = 0; q < quota; ++q) { const unsigned bit = tie & (0u - tie); kept |= bit; tie ^= bit; }
+        tie = kept;
+      }
+      quota -= min(have_t, quota);
+      sel[w] = lo[w] | tie;
+    }
+  }
+#undef WD_TC_PUSH
+  // C. peel the (at most K) ids off the mask in ascending order; read their positions (all reads in
+  //    flight together), rebuild the distances and form 64-bit keys (float bits of sqrt(d2) << 32 |
+  //    id); sort
+  int jj[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int which = sel[0] ? 0 : sel[1] ? 1 : sel[2] ? 2 : sel[3] ? 3 : 4;
+    const unsigned cur = sel[0] ? sel[0] : sel[1] ? sel[1] : sel[2] ? sel[2] : sel[3];
+    jj[k] = (which < 4) ? which * 32 + (__ffs(cur) - 1) : -1;
+    const unsigned cleared = cur & (cur - 1u);
+    sel[0] = (which == 0) ? cleared : sel[0];
+    sel[1] = (which == 1) ? cleared : sel[1];
+    sel[2] = (which == 2) ? cleared : sel[2];
+    sel[3] = (which == 3) ? cleared : sel[3];
+  }
+  float2 pp[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) pp[k] = cxy[jj[k] < 0 ? ag : jj[k]];
+  unsigned sb[KMAX];  // float bits of the float32 distance (>= 0: they order like unsigned integers)
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const float dx = xi - pp[k].x, dy = yi - pp[k].y;
+    sb[k] = (jj[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
+    nid[k] = jj[k];
+  }
+  tc_rank_entries<KMAX>(sb, rank);
+}
+
+// ---- exact fallback for more than 128 candidates (tc_knn_registers keeps a 128-bit mask): K passes,
+// each picks the smallest (float32 distance, index) key above the previous one.  Slow (K x N square
+// roots) and rare: only a lane with three candidates inside two key buckets at the cut gets here.
+template <int KMAX>
+__device__ __forceinline__ void tc_knn_scan(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX]) {
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
+  float pd = -1.0f;
+  int pj = -1;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    float best = __builtin_inff();
+    int bj = -1;
+    for (int j = 0; j < N; ++j) {
+      const float2 pc = cxy[j];
+      const float dx = xi - pc.x, dy = yi - pc.y;
+      const float d = sqrtf(dx * dx + dy * dy);
+      const bool above = (d > pd) || (d == pd && j > pj);
+      if (j != ag && above && d < best) { best = d; bj = j; }
+    }
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) nid[q] = (q == k) ? bj : nid[q];
+    if (bj < 0) break;  // fewer than K candidates (the remaining entries stay -1)
+    pd = best;
+    pj = bj;
+  }
+}
+
+// ---- neighbour search in ONE pass over the candidates: the candidate's id rides in the low 7 bits
+// of its squared distance (key = d2 bits with the low 7 bits replaced by j; non-negative floats order
+// like unsigned integers) and a v_med3_u32 chain keeps the K+3 smallest keys, so the ids come out of
+// the chain itself -- no second pass that rebuilds every distance to form a mask, no peeling of the
+// mask.  The 7 dropped bits make the chain's order approximate (buckets of 128 ulps of d2); the
+// exact answer is rebuilt from it:
+//   * with b = bucket of the K-th other agent in chain order, a candidate whose bucket is >= b + 2 is
+//     more than 128 ulps of d2 farther than each of the first K, i.e. strictly farther in float32
+//     sqrt too: it cannot be among the K nearest.  The answer is a subset of {bucket <= b + 1};
+//   * nearly always the first K+1 entries are far enough apart for the chain order to be the exact
+//     order (see "apart" below) and nothing more is computed.  Otherwise:
+//   * the chain tracks K+2 other agents.  If the last of them has a bucket >= b + 2, the subset is
+//     inside the first K+1 tracked entries.  The exact keys (float32 distance, id) of the first K are
+//     rebuilt and ranked by counting; when the (K+1)-th sits in the uncertain buckets (~3e-4 per
+//     agent) it is ranked against them as well, and the entries of rank < K are the answer, in the
+//     reference's order;
+//   * otherwise (three candidates within 256 ulps of d2 at the cut: ~1e-7 per agent) the lane
+//     returns false and repeats the search with tc_knn_registers.  It has to be that rare: a
+//     wavefront that repeats the search does so alone, latency-bound, and the whole launch waits for
+//     it (with one look-ahead entry less, ~9 of 4000 wavefronts did, and the tick got 5 us longer).
+__device__ __forceinline__ unsigned tc_umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// ---- the insertion chain over the candidates [j0, j1) (j0 a multiple of 4): L = self + K others + the look-ahead entries
+template <int L, int IDB>
+__device__ __forceinline__ void tc_chain_range(const float2 *cxy, float xi, float yi, int j0, int j1, unsigned (&S)[L]) {
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
+#define WD_TC_INSERT_KEY(d2v, jv)                                                          \
+  do {                                                                                     \
+    const unsigned key_ = (__float_as_uint(d2v) & ~IDM) | (unsigned)(jv);                  \
+    _Pragma("unroll") for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_); \
+    S[0] = min(S[0], key_);                                                                \
+  } while (0)
+  const int g0 = j0 >> 2, ng = j1 >> 2;
+  // groups of four candidates, two groups per trip, ping-pong: the positions of one group are in flight while the
+  // other goes through the chain, and no register is copied (a "load the next group, then rotate" loop is what
+  // the optimiser turns back into "load at the top, wait, use" when the start index is not a constant)
+#define WD_TC_INSERT_GROUP(grp, gidx)                                  \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                      \
+    const float dx = xi - (grp).p[u].x, dy = yi - (grp).p[u].y;        \
+    const float d2 = dx * dx + dy * dy;                                \
+    WD_TC_INSERT_KEY(d2, 4 * (gidx) + u);                              \
+  }
+  // the second half of the chain runs at the lowest priority, like the phases after the search
+  // (the caller entered at 2): measured 36.5 -> 35.6 us per tick with 1 here, another 0.2 us with
+  // 0 here and after the search; dropping after 1/8, 1/4 or 3/4 of the candidates, or not at
+  // all, is 0.1 .. 1 us slower
+  const int g_mid = (g0 + ng) >> 1;
+  TcP4 ga = tc_load4(cxy, 4 * g0), gb;
+  int g = g0;
+  for (; g + 2 <= ng; g += 2) {
+    gb = tc_load4(cxy, 4 * g + 4);
+    asm volatile("" ::: "memory");   // (keeps the load above the work below)
+    if (g >= g_mid && g < g_mid + 2) __builtin_amdgcn_s_setprio(0);
+    WD_TC_INSERT_GROUP(ga, g);
+    ga = tc_load4(cxy, 4 * g + 8);   // (the last prefetch lands in the padding behind the replica's positions)
+    asm volatile("" ::: "memory");
+    WD_TC_INSERT_GROUP(gb, g + 1);
+  }
+  if (g < ng) {
+    if (g >= g_mid) __builtin_amdgcn_s_setprio(0);
+    WD_TC_INSERT_GROUP(ga, g);
+  }
+#undef WD_TC_INSERT_GROUP
+  for (int j = max(4 * ng, j0); j < j1; ++j) {
+    const float2 pj = cxy[j];
+    const float dx = xi - pj.x, dy = yi - pj.y;
+    const float d2 = dx * dx + dy * dy;
+    WD_TC_INSERT_KEY(d2, j);
+  }
+#undef WD_TC_INSERT_KEY
+}
+
+// ---- the L smallest of the union of two ascending lists of L keys (this lane's S and the partner's P), ascending.
+// Both lists are padded to W = 16 (32, 64) entries with 0xffffffff -- still ascending --, then
+// c[k] = min(S[k], P[W-1-k]) are the W smallest of the 2W (an ascending against a descending sequence: the result
+// is bitonic) and a bitonic merge network sorts them: log2(W) x W/2 compare-exchanges (64 min / max for L <= 16)
+// against L x L median-of-three for inserting the partner's keys one by one.  (Padding AFTER the min step would
+// not do: a bitonic sequence followed by maxima is not bitonic.)
+__device__ __forceinline__ void tc_cex(unsigned &a, unsigned &b) {
+  const unsigned lo = min(a, b), hi = max(a, b);
+  a = lo;
+  b = hi;
+}
+template <int L>
+__device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned (&P)[L]) {
+  constexpr int W = (L <= 8) ? 8 : (L <= 16) ? 16 : (L <= 32) ? 32 : 64;
+  unsigned c[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const int q = W - 1 - k;  // partner entry
+    c[k] = (k < L && q < L) ? min(S[k], P[q]) : (k < L) ? S[k] : (q < L) ? P[q] : 0xffffffffu;
+  }
+#pragma unroll
+  for (int stride = W / 2; stride >= 1; stride >>= 1)
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      if ((k & stride) == 0) tc_cex(c[k], c[k + stride]);
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = c[k];
+}
+
+// ---- PREFILTERED search for replicas of more than 128 agents (round 4; one replica per block, K <= 12, used while at
+// least WD_TC_PRE_MIN_LIVE agents are in the game).  The chain costs 13 median-of-three (~3 cycles each with the VALU
+// saturated) + 6 cheap instructions per candidate and searcher and is VALU-bound on all sixteen wavefronts of a
+// 1005-agent replica: 80 % of its tick.  Agents move little per tick, so the searcher's K + 3 nearest others of the
+// PREVIOUS tick (32 bytes per agent in HBM, `knn_prev`) give a radius that holds the K nearest now (tc_knn_bound16):
+//   pass 1  every candidate: squared distance and ONE compare against the radius, shifted into a per-lane bit mask
+//           (v_cmp + v_addc: mask = 2 mask + bit) -- 7 instructions, 5 of them float32 add / mul at ~1.2 cycles;
+//   pass 2  the candidates whose bit is set (~15 per lane) go through the chain: 128 candidates = four mask words at
+//           a time, word by word every lane pops its own lowest set bit (lanes that ran out insert the pad position
+//           at +inf), as many trips as the fullest lane of the wavefront needs, U candidates per trip with the
+//           next trip's positions in flight.
+// At ~100 candidates this was measured and NOT adopted (a wash: pass 2 does not shrink with the number of
+// candidates); the break-even is at a few hundred.  What comes out is the K set the full chain
+// gives: the result is accepted only if the K-th other agent found lies at least TWO key buckets inside the radius
+// (`held` at the call site), so every candidate that was NOT listed is strictly farther in float32 distance than the
+// K-th -- it can neither enter the K set nor tie with its last member -- and every candidate that can is listed and
+// ranked exactly by tc_resolve_keys.  The look-ahead entries may differ from the full chain's (an unlisted
+// candidate reads +inf there), so the 'apart' / 'simple' shortcuts can fire where the full chain would have run the
+// exact ranking: that changes the work, not the K set, because a look-ahead entry only ever decides whether keys
+// INSIDE the listed range need the exact comparison, and an entry at +inf says "no tie beyond here", which is true.
+// That the radius really held the K nearest is CHECKED afterwards (the K-th other agent found must lie inside it), so
+// the content of `knn_prev` is only a hint: stale, restored or overwritten rows cost time (the wavefront repeats the
+// search with the full chain), never exactness.
+#define WD_TC_PRE_MIN_LIVE 200
+
+// The radius: 1.15 x (K + 3) / n x the LARGEST current squared distance to the n remembered agents that are still in
+// the game (their positions read NaN otherwise: v_max_f32 skips a NaN); none when fewer than 5 are.  With all K + 3 in
+// the game this lists a few more than K + 3 candidates, so the chain refills the remembered set with the K + 3 nearest
+// every tick; after remembered agents were tagged out the radius grows by the share that is missing.  A heuristic on
+// purpose (the radius that provably holds K candidates lists about K of them, leaves no spares to remember, and the
+// next tag leaves a stand-in from across the arena as the bound: experiments/offline/knn_prefilter_sim2.py), checked by
+// the caller.  Returns the bits of the radius, 0x7f800000 = none.
+template <int KMAX>
+__device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int pad_id, float xi, float yi, uint4 pa, uint4 pb,
+                                                   int K) {
+  constexpr int M = KMAX + 3;
+  static_assert(M <= 15, "the remembered neighbours are sixteen 16-bit ids per agent, K + 3 of them in use");
+  float2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14;
+#define WD_TC_PREV_POS(k, vec, word) \
+  if (k < M) p##k = xy_by_id[min((vec.word >> (16 * (k & 1))) & 0xffffu, (unsigned)pad_id)]  // out of the game / none / garbage: NaN
+  WD_TC_PREV_POS(0, pa, x); WD_TC_PREV_POS(1, pa, x); WD_TC_PREV_POS(2, pa, y); WD_TC_PREV_POS(3, pa, y);
+  WD_TC_PREV_POS(4, pa, z); WD_TC_PREV_POS(5, pa, z); WD_TC_PREV_POS(6, pa, w); WD_TC_PREV_POS(7, pa, w);
+  WD_TC_PREV_POS(8, pb, x); WD_TC_PREV_POS(9, pb, x); WD_TC_PREV_POS(10, pb, y); WD_TC_PREV_POS(11, pb, y);
+  WD_TC_PREV_POS(12, pb, z); WD_TC_PREV_POS(13, pb, z); WD_TC_PREV_POS(14, pb, w);
+#undef WD_TC_PREV_POS
+  float far = 0.0f;
+  unsigned n = 0u;
+#define WD_TC_PREV_DIST(k)                                                                                  \
+  if (k < M) {                                                                                              \
+    const float dx = xi - p##k.x, dy = yi - p##k.y;                                                         \
+    const float d2 = dx * dx + dy * dy;                                                                     \
+    far = fmaxf(far, d2); /* (maxnum: a NaN operand is ignored) */                                          \
+    asm("v_cmp_o_f32 vcc, %1, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(d2) : "vcc");       \
+  }
+  WD_TC_PREV_DIST(0) WD_TC_PREV_DIST(1) WD_TC_PREV_DIST(2) WD_TC_PREV_DIST(3) WD_TC_PREV_DIST(4)
+  WD_TC_PREV_DIST(5) WD_TC_PREV_DIST(6) WD_TC_PREV_DIST(7) WD_TC_PREV_DIST(8) WD_TC_PREV_DIST(9)
+  WD_TC_PREV_DIST(10) WD_TC_PREV_DIST(11) WD_TC_PREV_DIST(12) WD_TC_PREV_DIST(13) WD_TC_PREV_DIST(14)
+#undef WD_TC_PREV_DIST
+  const float T = far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
+  return (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;
+}
+
+// S: the L smallest keys among the candidates with d2 <= Tf, ascending; returns the (L+1)-th (one more id to remember)
+template <int L, int IDB, int U>
+__device__ __forceinline__ unsigned tc_chain_prefiltered(const float2 *cxy, float xi, float yi, int N, float Tf, int pad_idx,
+                                                         unsigned (&S)[L]) {
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+  unsigned extra = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
+#define WD_TC_MASK_PUSH(m, d2v) \
+  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(Tf) : "vcc")
+#define WD_TC_MASK_PUSH4(m, grp)                                       \
+  do {                                                                 \
+    float d_[4];                                                       \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                    \
+      const float dx = xi - (grp).p[u].x, dy = yi - (grp).p[u].y;      \
+      d_[u] = dx * dx + dy * dy;                                       \
+    }                                                                  \
+    WD_TC_MASK_PUSH(m, d_[0]); WD_TC_MASK_PUSH(m, d_[1]);              \
+    WD_TC_MASK_PUSH(m, d_[2]); WD_TC_MASK_PUSH(m, d_[3]);              \
+  } while (0)
+#define WD_TC_POP2(ix, px)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+    const bool have_ = (mw != 0u);                                                             \
+    ix[u] = have_ ? (unsigned)(top - (__ffs(mw) - 1)) : (unsigned)pad_idx;                     \
+    mw &= mw - 1u;                                                                             \
+    px[u] = cxy[ix[u]];                                                                        \
+  }
+#ifdef WD_TC_PROBES
+  int probe_trips = 0;
+#endif
+  for (int c0 = 0; c0 < N; c0 += 128) {  // wave-uniform
+    // ---- pass 1 of this chunk: candidate b of word w (candidates c0 + 32 w .. + nb - 1) ends on bit nb - 1 - b
+    unsigned mask[4] = {0u, 0u, 0u, 0u};
+    TcP4 ga = tc_load4(cxy, c0), gb;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = c0 + 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int nb = min(32, N - j0);
+        unsigned mu = 0u;
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {  // two groups of four per trip, ping-pong
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_MASK_PUSH4(mu, ga);
+          ga = tc_load4(cxy, j0 + b + 8);  // (at most 8 entries past the last candidate: padding)
+          WD_TC_MASK_PUSH4(mu, gb);
+        }
+        if (b + 4 <= nb) {
+          gb = tc_load4(cxy, j0 + b + 4);
+          WD_TC_MASK_PUSH4(mu, ga);
+          ga = gb;
+          b += 4;
+        }
+        for (; b < nb; ++b) {  // (only the last word can have a remainder)
+          const float2 pj = cxy[j0 + b];
+          const float dx = xi - pj.x, dy = yi - pj.y;
+          const float d2 = dx * dx + dy * dy;
+          WD_TC_MASK_PUSH(mu, d2);
+        }
+        mask[w] = mu;
+      }
+    }
+    // ---- pass 2 of this chunk
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j0 = c0 + 32 * w;
+      if (j0 < N) {  // wave-uniform
+        const int top = j0 + min(32, N - j0) - 1;  // the candidate on bit 0
+        unsigned mw = mask[w];
+        unsigned idx[U], idn[U];
+        float2 pj[U], pn[U];
+        bool more = __ballot(mw != 0u) != 0ull;  // wave-uniform: as many trips as the fullest lane needs
+        if (more) {
+          WD_TC_POP2(idn, pn);
+          while (more) {
+#ifdef WD_TC_PROBES
+            ++probe_trips;
+#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) { idx[u] = idn[u]; pj[u] = pn[u]; }
+            more = __ballot(mw != 0u) != 0ull;
+            if (more) { WD_TC_POP2(idn, pn); }
+            asm volatile("" ::: "memory");  // (keeps the reads above the work below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const float dx = xi - pj[u].x, dy = yi - pj[u].y;
+              const float d2 = dx * dx + dy * dy;
+              const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx[u];
+              extra = tc_umed3(S[L - 1], extra, key_);
+#pragma unroll
+              for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
+              S[0] = min(S[0], key_);
+            }
+          }
+        }
+      }
+    }
+  }
+#ifdef WD_TC_PROBES
+  WD_TC_PROBE_VAL(18, probe_trips);
+#endif
+#undef WD_TC_POP2
+#undef WD_TC_MASK_PUSH4
+#undef WD_TC_MASK_PUSH
+  return extra;
+}
+
+// ---- exact resolution for ONE searcher by the WHOLE wavefront (replicas of more than 128 agents; the K-pass scan
+// above took ~1.5 ms for a 1005-agent replica -- ten times the rest of the tick -- and a launch of 2000 replicas hit it
+// in ~11 wavefronts, so the launch waited for it on every tick).  The chain already located the cut: the answer lies
+// in the key buckets <= `zone_hi` (= the bucket of the K-th other agent + 1).  Lane l looks at candidates l, l + 64,
+// ...; the candidates inside the zone are packed (ballot + mbcnt: ascending index order) into a list in the
+// wavefront's staging buffer; each lane builds the exact (float32 distance, index) key of one listed candidate and
+// counts the smaller keys (LDS broadcast reads); rank r < K writes its index to out[r].  ~25 instructions per 64
+// candidates + ~4 per listed candidate.  Returns the number of candidates in the zone (> 64: not resolved, the
+// caller falls back to the scan -- a pile of agents on one spot).
+__device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, float sx, float sy, int self, unsigned zone_hi,
+                                               int idb, int K, unsigned char *scratch, int lane) {
+  unsigned short *const zl = (unsigned short *)scratch;                  // [64] candidate indices inside the zone
+  unsigned long long *const keys = (unsigned long long *)(scratch + 128);  // [64] exact keys
+  unsigned short *const out = (unsigned short *)(scratch + 128 + 512);     // [K] the K nearest in the reference's order
+  int cnt = 0;  // wave-uniform
+  for (int j0 = 0; j0 < n_cand; j0 += 64) {
+    const int j = j0 + lane;
+    bool in = false;
+    if (j < n_cand) {
+      const float2 pj = cxy[j];
+      const float dx = sx - pj.x, dy = sy - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      in = (j != self) && ((__float_as_uint(d2) >> idb) <= zone_hi);
+    }
+    const unsigned long long m = __ballot(in);
+    const int at = cnt + __popcll(m & ((1ull << lane) - 1ull));
+    if (in && at < 64) zl[at] = (unsigned short)j;
+    cnt += __popcll(m);
+  }
+  if (cnt > 64) return cnt;
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long mine = ~0ull;
+  if (lane < cnt) {
+    const int j = zl[lane];
+    const float2 pj = cxy[j];
+    const float dx = sx - pj.x, dy = sy - pj.y;
+    mine = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)j;
+    keys[lane] = mine;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  int r = 0;
+  for (int u = 0; u < cnt; ++u) r += (keys[u] < mine) ? 1 : 0;  // (wave-uniform address: a broadcast read)
+  if (lane < cnt && r < K) out[r] = (unsigned short)(mine & 0xffffu);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
+}
+
+// nid / rank have KMAX + 1 entries: entry k is one of the K nearest iff rank[k] < K
+// `in_order`: entry k is the k-th nearest for every k < K (rank[k] == k), and all K of them exist
+// IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512, 10 for up to 1024 (buckets of 2^IDB ulps of d2;
+// the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
+// at least 2^(IDB-1) - 1 ulps of the float32 distance)
+// S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
+// agent's own entry (the caller remembers their ids for the next tick's bound)
+template <int KMAX, int IDB, int L>
+__device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K, const unsigned (&S)[L],
+                                                unsigned (&o)[L - 1], int (&nid)[KMAX + 1], int (&rank)[KMAX + 1],
+                                                bool &in_order) {
+  static_assert(L >= KMAX + 3, "self + K others + two look-ahead entries");
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+  const float xi = cxy[ag].x, yi = cxy[ag].y;
+  // drop the agent's own entry (d2 = 0 exactly: key == ag).  It is the first entry unless a twin with
+  // a lower id sits on the same spot.
+  // (values first: with two producers of S -- the full and the prefiltered chain -- a select between two ELEMENTS of S
+  // becomes a select between their addresses, which keeps the two elements in scratch memory for the whole search)
+  unsigned sv[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    sv[k] = S[k];
+    asm volatile("" : "+v"(sv[k]));
+  }
+  if (__ballot(sv[0] != (unsigned)ag) == 0ull) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < L - 1; ++k) o[k] = sv[k + 1];
+  } else {
+    bool after = false;
+#pragma unroll
+    for (int k = 0; k < L - 1; ++k) {
+      after = after || (sv[k] == (unsigned)ag);
+      o[k] = after ? sv[k + 1] : sv[k];
+    }
+  }
+  // Chain order IS the reference's order wherever neighbouring keys are >= 383 apart: then their
+  // buckets differ by two or more (the ids in the low bits move a key by < 128), so the squared
+  // distances differ by more than 128 ulps and the float32 distances strictly.  When that holds for
+  // the first K entries and the one after them (all but ~0.2 % of the agents) the low bits of the
+  // first K keys are the answer as they stand -- no positions re-read, no square roots, no ranking.
+  unsigned gap = 0xffffffffu;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) gap = min(gap, o[k + 1] - o[k]);  // (two slots without a candidate are 0 apart)
+  unsigned oKth = o[KMAX - 1];  // the K-th other agent in chain order
+#pragma unroll
+  for (int k = 0; k < KMAX - 1; ++k) oKth = (k == K - 1) ? o[k] : oKth;
+  const bool apart = (gap >= 3u * (IDM + 1u) - 1u) && (oKth < 0x7f800000u);  // (and K others are in the game at all)
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    nid[k] = (k < K) ? (int)(o[k] & IDM) : -1;
+    rank[k] = k;
+  }
+  nid[KMAX] = -1;
+  rank[KMAX] = KMAX;
+  bool exact = true;
+  in_order = apart;
+  // A lane that is not `apart` nearly always has ONE pair of neighbouring keys that is too close, with clear gaps on
+  // either side of it: only that pair's order is open, and it is settled by comparing the two exact keys
+  // (float32 distance, index) -- a handful of instructions instead of the ranking of all K entries below, which the
+  // whole wavefront used to run with a few lanes active (+4.8 k cycles for the 4 % of the wavefronts that held such
+  // a lane: exactly the wavefronts the launch ends with, profiles/r04_phase_profile_*.txt).  The ranking remains
+  // for runs of three or more close keys, a close pair at the cut with a close look-ahead entry behind it, and
+  // fewer than K agents in the game.
+  bool simple = false;
+  if (!apart && oKth < 0x7f800000u) {
+    constexpr unsigned THR = 3u * (IDM + 1u) - 1u;
+    unsigned cm = 0u;  // bit k: keys k and k + 1 are close (k = K: the pair behind the cut)
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k)
+      if (k <= K) cm |= ((o[k + 1] - o[k] < THR) ? 1u : 0u) << k;
+    unsigned rel = cm & ((1u << K) - 1u);
+    const bool look_close = ((cm >> K) & 1u) != 0u;
+    simple = ((rel & (rel >> 1)) == 0u) && !(((rel >> (K - 1)) & 1u) != 0u && look_close);
+    if (simple) {
+      WD_TC_PROBE_VAL(23, 1);
+      while (rel) {
+        const int q = __ffs(rel) - 1;  // the pair (q, q + 1)
+        rel &= rel - 1u;
+        unsigned ka = o[0], kb = o[1];
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
+          ka = (q == k) ? o[k] : ka;
+          kb = (q == k) ? o[k + 1] : kb;
+        }
+        const int ia = (int)(ka & IDM), ib = (int)(kb & IDM);
+        const float2 pa = cxy[ia], pb = cxy[ib];
+        const float ax = xi - pa.x, ay = yi - pa.y, bx = xi - pb.x, by = yi - pb.y;
+        const unsigned sa = __float_as_uint(sqrtf(ax * ax + ay * ay)), sb = __float_as_uint(sqrtf(bx * bx + by * by));
+        // (indices are in ascending id order: the later entry goes first only when it is strictly closer)
+        if (sb < sa || (sb == sa && ib < ia)) {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) nid[k] = (k == q) ? ib : (k == q + 1 && k < K) ? ia : nid[k];
+        }
+      }
+      in_order = true;
+    }
+  }
+  if (!apart && !simple) {
+    WD_TC_PROBE_VAL(22, 1);
+    // the K-th, (K+1)-th and (K+2)-th other agent in chain order
+    unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
+#pragma unroll
+    for (int k = 0; k < KMAX - 1; ++k) {
+      oK = (k == K - 1) ? o[k] : oK;
+      oExtra = (k == K - 1) ? o[k + 1] : oExtra;
+      oLook = (k == K - 1) ? o[k + 2] : oLook;
+    }
+    const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
+    const unsigned cut = (oK >> IDB) + 2u;   // first bucket that is certainly outside
+    exact = (oK >= INVALID) || ((oLook >> IDB) >= cut);
+    // positions of the first K entries (all reads in flight together), exact keys, ranks
+    float2 pp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const bool valid = (k < K) && (o[k] < INVALID);
+      nid[k] = valid ? (int)(o[k] & IDM) : -1;
+      pp[k] = cxy[valid ? nid[k] : ag];
+    }
+    unsigned long long key64[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float dx = xi - pp[k].x, dy = yi - pp[k].y;
+      const unsigned sb = (nid[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
+      key64[k] = ((unsigned long long)sb << 32) | (unsigned)nid[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) rank[k] = k;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+      for (int j = i + 1; j < KMAX; ++j) {
+        const int c = (key64[j] < key64[i]) ? 1 : 0;
+        rank[i] += c;
+        rank[j] -= c;
+      }
+    nid[KMAX] = -1;
+    rank[KMAX] = KMAX;
+    // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
+    if (oK < INVALID && oExtra < INVALID && (oExtra >> IDB) < cut) {
+      const int idE = (int)(oExtra & IDM);
+      const float2 pe = cxy[idE];
+      const float dx = xi - pe.x, dy = yi - pe.y;
+      const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
+      int rE = K;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const int c = (i < K && keyE < key64[i]) ? 1 : 0;
+        rank[i] += c;
+        rE -= c;
+      }
+      nid[KMAX] = idE;
+      rank[KMAX] = rE;
+    }
+  }
+  return exact;
+}
+
+}  // namespace
