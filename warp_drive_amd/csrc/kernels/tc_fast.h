@@ -95,6 +95,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   }
   // the prefiltered search (tc_chain_prefiltered): on for big replicas while enough agents are in the game
   constexpr bool PRE = (IDB != 7) && (KMAX <= 12);
+  // equal distances are settled by agent id through the packed-index -> id table wherever the candidates of a block may be
+  // packed in another order than ascending id (tc_tie_order, tc_knn.h): replicas of more than 128 agents, one per block
+  constexpr bool TIE_TABLE = (IDB != 7);
   bool pre_on = false;  // block-uniform
   uint4 hint_a = make_uint4(~0u, ~0u, ~0u, ~0u), hint_b = hint_a;
   if constexpr (PRE) {
@@ -248,7 +251,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     // two-pass one (up to 128 candidates) / has the whole wavefront resolve it (more)
     unsigned o[L - 1];
     __builtin_amdgcn_s_setprio(1);
-    exact = tc_resolve_keys<KMAX, IDB, L>(sxy, ag, K, S, o, nid, rank, in_order);
+    exact = tc_resolve_keys<KMAX, IDB, L, TIE_TABLE>(sxy, ag, K, S, o, nid, rank, in_order, l.cid);
     WD_TC_PROBE(10);
     {  // the last key bucket the answer can come from: the K-th other agent's + 1
       unsigned oKth = o[KMAX - 1];
@@ -305,7 +308,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my), fl));
         const unsigned zh = (unsigned)__builtin_amdgcn_readlane((int)zone_hi, fl);
         const int self = __builtin_amdgcn_readlane(ag, fl);
-        const int cnt = tc_zone_resolve(sxy, n_cand, sx, sy, self, zh, IDB, K, (unsigned char *)stage, lane);
+        const int cnt = tc_zone_resolve<TIE_TABLE>(sxy, n_cand, sx, sy, self, zh, IDB, K, (unsigned char *)stage, lane, l.cid);
         if (cnt > 64) {
           unresolved |= 1ull << fl;
         } else {
@@ -324,7 +327,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         int nid2[KMAX];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) nid2[k] = -1;
-        tc_knn_scan<KMAX>(sxy, ag, n_cand, K, nid2);  // (entries in the reference's order)
+        tc_knn_scan<KMAX, TIE_TABLE>(sxy, ag, n_cand, K, nid2, l.cid);  // (entries in the reference's order)
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) { nid[k] = nid2[k]; rank[k] = k; }
         nid[KMAX] = -1;

@@ -11,6 +11,19 @@ namespace {
 //                   fast path: N <= 512, partial observations, K <= KMAX
 // =====================================================================================
 
+// ---- THE tie-break order of a candidate index.  The reference orders neighbours by (float32 distance, agent id)
+// (heapq.nsmallest on (distance, id) tuples, tag_continuous.py:422-444).  Every routine below works on candidate INDICES
+// (positions in the packed candidate array) and settles equal distances through this one function:
+//   TABLE == false  candidates are packed in ascending agent-id order (always so up to 128 agents; the identity folds away)
+//   TABLE == true   `tie` = the packed-index -> agent-id table (`TcFastLds::cid`, tie[1 + idx]): candidates may be packed
+//                   in ANY order -- e.g. by grid cell (tc_fast.h, replicas of more than 128 agents); null = no table
+//                   (several replicas per block: never packed, index = id)
+template <bool TABLE>
+__device__ __forceinline__ int tc_tie_order(const short *tie, int idx) {
+  if constexpr (TABLE) return tie ? (int)tie[1 + idx] : idx;
+  else return idx;
+}
+
 struct TcP4 {
   float2 p[4];
 };
@@ -46,6 +59,8 @@ __device__ __forceinline__ void tc_rank_entries(const unsigned (&sb)[KMAX], int 
     }
 }
 
+// (candidates in ascending agent-id order only -- tc_tie_order<false>: it peels its masks in index order and ranks equal
+// distances by index; the caller uses it up to 128 candidates, which are never packed in another order)
 template <int KMAX>
 __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX],
                                                  int (&rank)[KMAX]) {
@@ -273,27 +288,35 @@ __device__ __forceinline__ void tc_knn_registers(const float2 *cxy, int ag, int 
 // ---- exact fallback for more than 128 candidates (tc_knn_registers keeps a 128-bit mask): K passes,
 // each picks the smallest (float32 distance, index) key above the previous one.  Slow (K x N square
 // roots) and rare: only a lane with three candidates inside two key buckets at the cut gets here.
-template <int KMAX>
-__device__ __forceinline__ void tc_knn_scan(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX]) {
+template <int KMAX, bool TABLE = false>
+__device__ __forceinline__ void tc_knn_scan(const float2 *cxy, int ag, int N, int K, int (&nid)[KMAX],
+                                            const short *tie = nullptr) {
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   float pd = -1.0f;
-  int pj = -1;
+  int pj = -1, pt = -1;  // the previous pick: index and tie-break order
 #pragma unroll 1
   for (int k = 0; k < K; ++k) {
     float best = __builtin_inff();
-    int bj = -1;
+    int bj = -1, bt = 0x7fffffff;
     for (int j = 0; j < N; ++j) {
       const float2 pc = cxy[j];
       const float dx = xi - pc.x, dy = yi - pc.y;
       const float d = sqrtf(dx * dx + dy * dy);
-      const bool above = (d > pd) || (d == pd && j > pj);
-      if (j != ag && above && d < best) { best = d; bj = j; }
+      if constexpr (TABLE) {  // smallest (distance, id) key above the previous pick's
+        const int tj = tc_tie_order<true>(tie, j);
+        const bool above = (d > pd) || (d == pd && tj > pt);
+        if (j != ag && above && (d < best || (d == best && tj < bt))) { best = d; bj = j; bt = tj; }
+      } else {               // ascending index = ascending id: the first minimum wins
+        const bool above = (d > pd) || (d == pd && j > pj);
+        if (j != ag && above && d < best) { best = d; bj = j; }
+      }
     }
 #pragma unroll
     for (int q = 0; q < KMAX; ++q) nid[q] = (q == k) ? bj : nid[q];
     if (bj < 0) break;  // fewer than K candidates (the remaining entries stay -1)
     pd = best;
     pj = bj;
+    pt = bt;
   }
 }
 
@@ -582,8 +605,9 @@ __device__ __forceinline__ unsigned tc_chain_prefiltered(const float2 *cxy, floa
 // counts the smaller keys (LDS broadcast reads); rank r < K writes its index to out[r].  ~25 instructions per 64
 // candidates + ~4 per listed candidate.  Returns the number of candidates in the zone (> 64: not resolved, the
 // caller falls back to the scan -- a pile of agents on one spot).
+template <bool TABLE = false>
 __device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, float sx, float sy, int self, unsigned zone_hi,
-                                               int idb, int K, unsigned char *scratch, int lane) {
+                                               int idb, int K, unsigned char *scratch, int lane, const short *tie = nullptr) {
   unsigned short *const zl = (unsigned short *)scratch;                  // [64] candidate indices inside the zone
   unsigned long long *const keys = (unsigned long long *)(scratch + 128);  // [64] exact keys
   unsigned short *const out = (unsigned short *)(scratch + 128 + 512);     // [K] the K nearest in the reference's order
@@ -610,7 +634,9 @@ __device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, fl
     const int j = zl[lane];
     const float2 pj = cxy[j];
     const float dx = sx - pj.x, dy = sy - pj.y;
-    mine = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)j;
+    // (float32 distance, tie-break order, index): the index rides along below the order and never decides
+    mine = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) |
+           (TABLE ? ((unsigned)tc_tie_order<TABLE>(tie, j) << 16) : 0u) | (unsigned)j;
     keys[lane] = mine;
   }
   asm volatile("" ::: "memory");
@@ -630,10 +656,10 @@ __device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, fl
 // at least 2^(IDB-1) - 1 ulps of the float32 distance)
 // S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
 // agent's own entry (the caller remembers their ids for the next tick's bound)
-template <int KMAX, int IDB, int L>
+template <int KMAX, int IDB, int L, bool TABLE = false>
 __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K, const unsigned (&S)[L],
                                                 unsigned (&o)[L - 1], int (&nid)[KMAX + 1], int (&rank)[KMAX + 1],
-                                                bool &in_order) {
+                                                bool &in_order, const short *tie = nullptr) {
   static_assert(L >= KMAX + 3, "self + K others + two look-ahead entries");
   constexpr unsigned IDM = (1u << IDB) - 1u;
   const float xi = cxy[ag].x, yi = cxy[ag].y;
@@ -712,8 +738,8 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
         const float2 pa = cxy[ia], pb = cxy[ib];
         const float ax = xi - pa.x, ay = yi - pa.y, bx = xi - pb.x, by = yi - pb.y;
         const unsigned sa = __float_as_uint(sqrtf(ax * ax + ay * ay)), sb = __float_as_uint(sqrtf(bx * bx + by * by));
-        // (indices are in ascending id order: the later entry goes first only when it is strictly closer)
-        if (sb < sa || (sb == sa && ib < ia)) {
+        // (equal float32 distances: the lower agent id goes first)
+        if (sb < sa || (sb == sa && tc_tie_order<TABLE>(tie, ib) < tc_tie_order<TABLE>(tie, ia))) {
 #pragma unroll
           for (int k = 0; k < KMAX; ++k) nid[k] = (k == q) ? ib : (k == q + 1 && k < K) ? ia : nid[k];
         }
@@ -747,7 +773,7 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
     for (int k = 0; k < KMAX; ++k) {
       const float dx = xi - pp[k].x, dy = yi - pp[k].y;
       const unsigned sb = (nid[k] >= 0) ? __float_as_uint(sqrtf(dx * dx + dy * dy)) : 0x7f800000u;
-      key64[k] = ((unsigned long long)sb << 32) | (unsigned)nid[k];
+      key64[k] = ((unsigned long long)sb << 32) | (unsigned)(nid[k] < 0 ? nid[k] : tc_tie_order<TABLE>(tie, nid[k]));
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) rank[k] = k;
@@ -766,7 +792,8 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
       const int idE = (int)(oExtra & IDM);
       const float2 pe = cxy[idE];
       const float dx = xi - pe.x, dy = yi - pe.y;
-      const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) | (unsigned)idE;
+      const unsigned long long keyE = ((unsigned long long)__float_as_uint(sqrtf(dx * dx + dy * dy)) << 32) |
+                                      (unsigned)tc_tie_order<TABLE>(tie, idE);
       int rE = K;
 #pragma unroll
       for (int i = 0; i < KMAX; ++i) {
