@@ -11,9 +11,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PROF_DIR = os.path.join(ROOT, "build", "variants", "prof")
+# WD_PROF_DIR / WD_PROF_SRC: another variant directory / another kernel source directory (e.g. an earlier commit's
+# csrc/kernels exported with `git archive`), for before / after profiles of one change
+PROF_DIR = os.environ.get("WD_PROF_DIR", os.path.join(ROOT, "build", "variants", "prof"))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from warp_drive_amd import build as wb
+
+    if os.environ.get("WD_PROF_SRC"):
+        wb.KDIR = os.environ["WD_PROF_SRC"]
+        wb.KERNEL_FLAGS = [f"-I{wb.KDIR}" if f.startswith("-I") else f for f in wb.KERNEL_FLAGS]
 
     os.makedirs(PROF_DIR, exist_ok=True)
     for out, (unit, flags) in wb.UNITS.items():
@@ -89,6 +95,17 @@ for k in range(1, 16):
 names = ["start", "loads issued+tables", "sampled", "barrier1", "moved", "barrier2", "tags", "search: radius", "search: prefiltered chain",
          "search: full chain", "search: keys resolved", "search: ids, remember", "id rows + barrier + nearest ids flushed",
          "obs gathered+flushed", "barrier3", "rewards/end"]
+if pre.any():  # big replicas: the wavefronts of a block differ (cell-sorted packing: border cells see fewer candidates)
+    sp = st[pre]
+    print(f"--- all {pre.sum()} prefiltered wavefronts: mean / p10 / p50 / p90 / max shader cycles")
+    for k in (7, 8, 9, 10, 11):
+        d = sp[:, k] - sp[:, k - 1]
+        print(f"  {names[k]:<40} {d.mean():9.0f} {np.percentile(d, 10):9.0f} {np.percentile(d, 50):9.0f} {np.percentile(d, 90):9.0f} {d.max():9.0f}")
+    d = sp[:, 11] - sp[:, 6]
+    print(f"  {'search, all of it':<40} {d.mean():9.0f} {np.percentile(d, 10):9.0f} {np.percentile(d, 50):9.0f} {np.percentile(d, 90):9.0f} {d.max():9.0f}")
+    blk = np.nonzero(pre)[0] // WPB
+    slow = np.array([d[blk == b].max() for b in np.unique(blk)])
+    print(f"  slowest searcher of each block: mean {slow.mean():.0f} p50 {np.percentile(slow, 50):.0f} p90 {np.percentile(slow, 90):.0f}")
 for wv, label in ((0, "wave 0 of each block"), (WPB - 1, "the last wave of each block")):
     s = st[wv::WPB]
     ok = (s[:, 6] > 0) & (s[:, 15] > 0)

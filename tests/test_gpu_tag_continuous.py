@@ -695,6 +695,58 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
             np.testing.assert_array_equal(got[e], want[e], err_msg=f"K={K} t={t} case (delta, swap, triple)={cases[e]}")
 
 
+@pytest.mark.parametrize("side,spacing,kernel", [(32, 0.625, "HipTagContinuousStep_K10_N1024"),
+                                                 (20, 1.0, "HipTagContinuousStep_K10_N512")])
+def test_cell_sorted_search_on_a_lattice_of_exact_ties(side, spacing, kernel):
+    """Replicas of more than 128 agents pack the agents in the game by GRID CELL for the neighbour search (tc_knn.h
+    "CELL-SORTED packing": a wavefront's searchers are neighbours in space and look at the cell rows around them only),
+    so the order of the candidates has nothing to do with their ids any more, while the reference breaks equal distances
+    by id (tag_continuous.py:422-444).  side x side agents stand still on a square lattice, ids dealt at random: every
+    agent has 4 neighbours at distance 1, 4 at sqrt(2), 4 at 2, 8 at sqrt(5) lattice steps -- K = 10 cuts the third ring,
+    K-th and (K+1)-th candidate are EXACTLY as far, everywhere, and which two of the four get in is decided by id alone.
+    Every fourth lattice line is a cell border (cells of 2.5 / 4.0 units), the arena's border rows have fewer neighbours.
+    Four ticks (the first searches inside the cell cover alone, the later ones inside the remembered neighbours' radius),
+    observations and nearest_neighbor_ids compared with tolerance 0 -- no near-tie allowance."""
+    from tests.hip_harness import OBS, pull, push_actions
+
+    n = side * side
+    cfg = dict(num_taggers=4, num_runners=n - 4, grid_length=20.0, episode_length=9, seed=1,
+               max_acceleration=0.1, min_acceleration=-0.1, num_acceleration_levels=4, num_turn_levels=4,
+               use_full_observation=False, num_other_agents_observed=10, tagging_distance=1e-5,
+               runner_exits_game_after_tagged=True)
+    E = 3
+    w = _mk(cfg, E)
+    assert w.env.resolve_step_function_name("HipTagContinuousStep") == kernel
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    f32 = np.float32
+    rng = np.random.default_rng(side)
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    xs, ys = np.zeros((E, n), f32), np.zeros((E, n), f32)
+    for e in range(E):
+        perm = rng.permutation(n)
+        xs[e, perm] = (gx.ravel() * spacing).astype(f32)
+        ys[e, perm] = (gy.ravel() * spacing).astype(f32)
+    state = dict(loc_x=xs, loc_y=ys, speed=np.zeros((E, n), f32), direction=np.zeros((E, n), f32),
+                 acceleration=np.zeros((E, n), f32))
+    orc.set_state(**state)
+    _push_state(w, **state)
+    act = np.zeros((E, n, 2), dtype=np.int32)
+    act[..., 0] = int(np.argmin(np.abs(orc.acceleration_actions)))
+    act[..., 1] = int(np.argmin(np.abs(orc.turn_actions)))
+    for t in range(4):
+        push_actions(w, act)
+        w.step_all_envs()
+        orc.step(act)
+        np.testing.assert_array_equal(pull(w, "loc_x"), xs, err_msg="the agents were to stand still")
+        np.testing.assert_array_equal(pull(w, OBS), orc.obs.astype(np.float32), err_msg=f"observations t={t}")
+        np.testing.assert_array_equal(pull(w, "nearest_neighbor_ids").reshape(orc.nearest_ids.shape), orc.nearest_ids,
+                                      err_msg=f"nearest_neighbor_ids t={t}")
+    # the construction is what it claims: agent rows away from the border hold an exact tie at the cut
+    d = orc.neighbor_dist[0]
+    srt = np.sort(d, axis=1)
+    assert (srt[:, 9] == srt[:, 10]).mean() > 0.8
+
+
 @pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (300, 10, False), (500, 10, False),
                                                   (525, 5, False), (1020, 3, False), (1000, 10, False), (700, 16, False),
                                                   (600, 20, False)])

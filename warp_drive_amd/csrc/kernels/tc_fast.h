@@ -74,6 +74,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   int2 sampled = in.sampled;
   const unsigned long long live_mask = __ballot(active && in.sg != 0);
   if (compact && lane == 0) tb.live_cnt[wave] = __popcll(live_mask);
+  if constexpr ((IDB != 7) && (KMAX <= 12)) {  // (the cell-sorted packing's counters, see below)
+    if (compact && tid < 64) tb.cell_cnt[tid] = 0;
+  }
   if (FUSED) {
     if (active && ag == 0) a.done[env] = 0;  // a replica that finished (and was reset) last tick
     if (SAMPLE) sampled = tc_sample_heads(a, fz, in, active, gi, li, slab_acc, slab_turn, n_acc, n_turn, env0, epb);
@@ -99,13 +102,22 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // packed in another order than ascending id (tc_tie_order, tc_knn.h): replicas of more than 128 agents, one per block
   constexpr bool TIE_TABLE = (IDB != 7);
   bool pre_on = false;  // block-uniform
+  int cells_C = 0;      // block-uniform: side of the cell grid the agents in the game are packed by (0: by id)
+  float cell_len = 0.0f, cell_inv = 0.0f;
+  int my_cell = 0, my_cell_slot = 0;  // this lane's agent: its cell and its arrival number in it
   uint4 hint_a = make_uint4(~0u, ~0u, ~0u, ~0u), hint_b = hint_a;
   if constexpr (PRE) {
-    pre_on = compact && (a.knn_prev != nullptr) && (n_live >= WD_TC_PRE_MIN_LIVE) && (l.stage_dwords >= 512);
+    pre_on = compact && (a.knn_prev != nullptr) && (n_live >= WD_TC_PRE_MIN_LIVE) && (l.stage_dwords >= WD_TC_LIST_DWORDS);
     if (pre_on && active && in.sg != 0) {  // (in flight during the move)
       const uint4 *const h = (const uint4 *)(a.knn_prev + (size_t)(env * N + ag) * 8);
       hint_a = h[0];
       hint_b = h[1];
+    }
+    // ... and then the agents in the game are packed by grid cell, not by id (tc_knn.h "CELL-SORTED packing")
+    if (pre_on) {
+      cells_C = tc_cell_grid(n_live, K);
+      cell_len = a.grid_length / (float)max(cells_C, 1);
+      cell_inv = (float)cells_C / a.grid_length;
     }
   }
 
@@ -122,12 +134,23 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     l.xy[el * NP + ag] = make_float2(sg ? m.x : (PRE && pre_on ? __builtin_nanf("") : WD_BIG), m.y);
     if (compact) {
       if (sg) {
-        l.xyc[my_c] = make_float2(m.x, m.y);
-        l.cid[1 + my_c] = (short)ag;
-        if (PRE && pre_on) {  // the hint goes to the lane that searches for this agent: slot my_c & 63 of wavefront my_c >> 6
-          uint4 *const slot = (uint4 *)(l.stage + (size_t)(my_c >> 6) * l.stage_dwords) + 2 * (my_c & 63);
-          slot[0] = hint_a;
-          slot[1] = hint_b;
+        bool by_cell = false;
+        if constexpr (PRE) {
+          if (cells_C != 0) {  // its packed place is known after the barrier (counting sort)
+            const int2 c = tc_cell_xy(m.x, m.y, cell_inv, cells_C);
+            my_cell = c.y * cells_C + c.x;
+            my_cell_slot = atomicAdd(&tb.cell_cnt[my_cell], 1);
+            by_cell = true;
+          }
+        }
+        if (!by_cell) {
+          l.xyc[my_c] = make_float2(m.x, m.y);
+          l.cid[1 + my_c] = (short)ag;
+          if (PRE && pre_on) {  // the hint goes to the lane that searches for this agent: slot my_c & 63 of wavefront my_c >> 6
+            uint4 *const slot = (uint4 *)(l.stage + (size_t)(my_c >> 6) * l.stage_dwords) + 2 * (my_c & 63);
+            slot[0] = hint_a;
+            slot[1] = hint_b;
+          }
         }
       }
       if (ag == 0) {
@@ -155,12 +178,35 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   WD_TC_PROBE(4);
   __syncthreads();
   WD_TC_PROBE(5);
+  int cell_incl = 0;  // lane c: agents in the game in cells 0 .. c (every wavefront scans the 64 counters for itself)
+  if constexpr (PRE) {
+    if (cells_C != 0) {  // block-uniform
+      const int cnt = tb.cell_cnt[lane];
+      cell_incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(cell_incl, d, 64);
+        cell_incl += (lane >= d) ? up : 0;
+      }
+      my_c = __builtin_amdgcn_ds_bpermute(my_cell << 2, cell_incl - cnt) + my_cell_slot;
+      if (active && sg != 0) {
+        l.xyc[my_c] = make_float2(my_x, my_y);
+        l.cid[1 + my_c] = (short)ag;
+        uint4 *const slot = (uint4 *)(l.stage + (size_t)(my_c >> 6) * l.stage_dwords) + 2 * (my_c & 63);
+        slot[0] = hint_a;
+        slot[1] = hint_b;
+      }
+    }
+  }
 
   // ------------------------------------------------------------ tags (counts are read after the
   // barrier that follows the gather)
   bool tagged = false;
   if (is_runner)
     tagged = tc_find_tag(a, tb, l.xy + el * NP, l.tagcnt + el * N, &tb.nrun[el], n_taggers, my_x, my_y);
+  if constexpr (PRE) {
+    if (cells_C != 0) __syncthreads();  // the packed positions, ids and hints are in place
+  }
 
   // ------------------------------------------------------------ search
   WD_TC_PROBE(6);
@@ -195,11 +241,16 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     if (pre_on) {  // block-uniform
       unsigned Tb = 0u;
       float sx = 0.0f, sy = 0.0f;
+      int2 scell = make_int2(0, 0);
       if (searcher) {
         const uint4 *const slot = (const uint4 *)stage + 2 * lane;
         const uint4 pa = slot[0], pb = slot[1];
         sx = sxy[ag].x; sy = sxy[ag].y;
         Tb = tc_knn_bound16<KMAX>(l.xy, N, sx, sy, pa, pb, K);
+        if (cells_C != 0) {  // nothing outside the searcher's 3 x 3 cell block is inside the radius
+          scell = tc_cell_xy(sx, sy, cell_inv, cells_C);
+          Tb = min(Tb, tc_cell_cover2(sx, sy, scell, cell_len, cells_C));
+        }
       }
       WD_TC_PROBE(7);
       // every searcher of the wavefront has a radius -- and there IS a searcher: a wavefront without one (tid >=
@@ -208,8 +259,69 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       if (__ballot(searcher) != 0ull && __ballot(searcher && Tb == 0x7f800000u) == 0ull) {
         // (lanes without a searcher: radius -1, nothing listed; they only take part in the wave-wide votes)
         // (candidates popped per trip: the fullest lane of a 32-candidate word holds ~2 at 1000 agents, ~4 at 500)
-        constexpr int POPS = (IDB == 10) ? 1 : 2;
-        extra = tc_chain_prefiltered<L, IDB, POPS>(sxy, sx, sy, n_cand, searcher ? __uint_as_float(Tb) : -1.0f, n_cand, S);
+        const float Tf = searcher ? __uint_as_float(Tb) : -1.0f;
+#pragma unroll
+        for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
+        // Packed by id: ONE run, every candidate.  Packed by cell: the wavefront's searchers hold consecutive packed places,
+        // i.e. the cells (x_lo, y_lo) .. (x_hi, y_hi) in row-major order; per cell row r, the cells within one column of any
+        // of them in the rows r - 1 .. r + 1 are one run of packed places (the hull of the columns).  Runs are taken in
+        // ascending order, widened to multiples of 4 places, never overlapping (a candidate must not enter the chain
+        // twice) and joined where they touch.  All of it is scalar work; pass 1 and pass 2 have ONE call site each:
+        // pass 1 lists up to WD_TC_LIST_CAP words of candidates (from one run or several), pass 2 empties the lists.
+        const int C = cells_C;
+        int r = 0, r_end = -1, run0 = 0, run1 = n_cand, x_lo = 0, y_lo = 0, x_hi = 0, y_hi = 0;
+        if (C != 0) {
+          const int last = min(63, __builtin_amdgcn_readfirstlane(n_live) - 1 - 64 * wave);
+          x_lo = __builtin_amdgcn_readfirstlane(scell.x); y_lo = __builtin_amdgcn_readfirstlane(scell.y);
+          x_hi = __builtin_amdgcn_readlane(scell.x, last); y_hi = __builtin_amdgcn_readlane(scell.y, last);
+          r = max(0, y_lo - 1);
+          r_end = min(C - 1, y_hi + 1);
+          run1 = 0;
+        }
+        const TcPreList pl = tc_pre_list(stage, lane);
+        int j = 0, j_end = 0;       // the part of the current run that pass 1 has not seen
+        int listed = 0, words = 0;  // per lane: words in its list; wave-uniform: words since the last round of pass 2
+        int probe_trips = 0;
+        bool finished = false;
+        while (!finished) {
+          while (words < WD_TC_LIST_CAP) {
+            if (j >= j_end) {  // the next run
+              bool flush = false;
+              int p0 = 0, p1 = 0;
+              while (!flush && r <= r_end) {
+                int lo = C, hi = -1;
+                for (int yy = max(y_lo, r - 1); yy <= min(y_hi, r + 1); ++yy) {
+                  lo = min(lo, yy == y_lo ? x_lo : 0);
+                  hi = max(hi, yy == y_hi ? x_hi : C - 1);
+                }
+                const int first_cell = r * C + max(0, lo - 1), last_cell = r * C + min(C - 1, hi + 1);
+                ++r;
+                if (hi < 0) continue;
+                const int b = first_cell == 0 ? 0 : __builtin_amdgcn_readlane(cell_incl, max(first_cell, 1) - 1);
+                const int e = __builtin_amdgcn_readlane(cell_incl, last_cell);
+                const int j0 = max(run1, b & ~3), j1 = min(n_cand, (e + 3) & ~3);
+                if (j1 <= j0) continue;
+                if (run1 > run0 && j0 != run1) { p0 = run0; p1 = run1; flush = true; run0 = j0; run1 = j1; }
+                else if (run1 > run0) run1 = j1;
+                else { run0 = j0; run1 = j1; }
+              }
+              if (!flush) {
+                if (run1 <= run0) { finished = true; break; }
+                p0 = run0; p1 = run1; run0 = run1;
+              }
+              j = p0;
+              j_end = p1;
+            }
+            const int j_stop = min(j_end, j + 32 * (WD_TC_LIST_CAP - words));
+            tc_pre_pass1(sxy, sx, sy, j, j_stop, Tf, pl, listed);
+            words += (j_stop - j + 31) >> 5;
+            j = j_stop;
+          }
+          if (words != 0) tc_pre_pass2<L, IDB>(sxy, sx, sy, n_cand, pl, listed, S, extra, probe_trips);
+          listed = 0;
+          words = 0;
+        }
+        WD_TC_PROBE_VAL(18, probe_trips);
         // the radius held the K nearest iff the K-th other agent found (entry K with the agent's own) lies at least
         // two key buckets inside it: everything that was not listed is then past the buckets tc_resolve_keys looks at
         unsigned sK = S[KMAX];

@@ -434,10 +434,10 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
 // PREVIOUS tick (32 bytes per agent in HBM, `knn_prev`) give a radius that holds the K nearest now (tc_knn_bound16):
 //   pass 1  every candidate: squared distance and ONE compare against the radius, shifted into a per-lane bit mask
 //           (v_cmp + v_addc: mask = 2 mask + bit) -- 7 instructions, 5 of them float32 add / mul at ~1.2 cycles;
-//   pass 2  the candidates whose bit is set (~15 per lane) go through the chain: 128 candidates = four mask words at
-//           a time, word by word every lane pops its own lowest set bit (lanes that ran out insert the pad position
-//           at +inf), as many trips as the fullest lane of the wavefront needs, U candidates per trip with the
-//           next trip's positions in flight.
+//   pass 2  the candidates whose bit is set (~15 per lane) go through the chain: every lane pops its own lowest set bit
+//           from its own list of non-empty mask words (round 6: tc_pre_pass2; lanes that ran out insert the pad
+//           position at +inf), as many trips as the fullest lane of the wavefront needs, with the next trip's
+//           position in flight.
 // At ~100 candidates this was measured and NOT adopted (a wash: pass 2 does not shrink with the number of
 // candidates); the break-even is at a few hundred.  What comes out is the K set the full chain
 // gives: the result is accepted only if the K-th other agent found lies at least TWO key buckets inside the radius
@@ -452,13 +452,18 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
 // search with the full chain), never exactness.
 #define WD_TC_PRE_MIN_LIVE 200
 
-// The radius: 1.15 x (K + 3) / n x the LARGEST current squared distance to the n remembered agents that are still in
-// the game (their positions read NaN otherwise: v_max_f32 skips a NaN); none when fewer than 5 are.  With all K + 3 in
-// the game this lists a few more than K + 3 candidates, so the chain refills the remembered set with the K + 3 nearest
-// every tick; after remembered agents were tagged out the radius grows by the share that is missing.  A heuristic on
-// purpose (the radius that provably holds K candidates lists about K of them, leaves no spares to remember, and the
-// next tag leaves a stand-in from across the arena as the bound: experiments/offline/knn_prefilter_sim2.py), checked by
-// the caller.  Returns the bits of the radius, 0x7f800000 = none.
+// The radius, from the CURRENT squared distances to the n remembered agents that are still in the game (their positions
+// read NaN otherwise; none when fewer than 5 are):
+//   n >= K + 2   1.15 x the THIRD LARGEST of them (round 6).  It is the (n - 2)-th smallest, n - 2 >= K, so K others are
+//                inside it for sure; with all K + 3 in the game it lists the K + 1 nearest of the remembered and whoever came
+//                closer since -- ~21 candidates instead of the ~35 the largest distance listed: agents move up to a
+//                neighbourhood radius per tick, and ONE remembered agent that ran away used to set the radius
+//                (experiments/offline/knn_cell_sort_sim.py; pass 2 takes as many trips as the fullest lane lists);
+//   otherwise    1.15 x (K + 3) / n x the largest: after remembered agents were tagged out the radius grows by the share
+//                that is missing.
+// Fewer than K + 3 listed means fewer remembered for the next tick, which falls back to the second form: self-correcting.
+// A heuristic on purpose (experiments/offline/knn_prefilter_sim2.py), checked by the caller.  Returns the bits of the
+// radius, 0x7f800000 = none.
 template <int KMAX>
 __device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int pad_id, float xi, float yi, uint4 pa, uint4 pb,
                                                    int K) {
@@ -472,33 +477,89 @@ __device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int p
   WD_TC_PREV_POS(8, pb, x); WD_TC_PREV_POS(9, pb, x); WD_TC_PREV_POS(10, pb, y); WD_TC_PREV_POS(11, pb, y);
   WD_TC_PREV_POS(12, pb, z); WD_TC_PREV_POS(13, pb, z); WD_TC_PREV_POS(14, pb, w);
 #undef WD_TC_PREV_POS
-  float far = 0.0f;
+  float far = 0.0f, far2 = 0.0f, far3 = 0.0f;  // the three largest, descending
   unsigned n = 0u;
 #define WD_TC_PREV_DIST(k)                                                                                  \
   if (k < M) {                                                                                              \
     const float dx = xi - p##k.x, dy = yi - p##k.y;                                                         \
     const float d2 = dx * dx + dy * dy;                                                                     \
-    far = fmaxf(far, d2); /* (maxnum: a NaN operand is ignored) */                                          \
+    const float dz = fmaxf(d2, 0.0f); /* (maxnum: a NaN operand is ignored -- out of the game counts as 0) */ \
+    far3 = __builtin_amdgcn_fmed3f(far2, far3, dz);                                                         \
+    far2 = __builtin_amdgcn_fmed3f(far, far2, dz);                                                          \
+    far = fmaxf(far, dz);                                                                                   \
     asm("v_cmp_o_f32 vcc, %1, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n) : "v"(d2) : "vcc");       \
   }
   WD_TC_PREV_DIST(0) WD_TC_PREV_DIST(1) WD_TC_PREV_DIST(2) WD_TC_PREV_DIST(3) WD_TC_PREV_DIST(4)
   WD_TC_PREV_DIST(5) WD_TC_PREV_DIST(6) WD_TC_PREV_DIST(7) WD_TC_PREV_DIST(8) WD_TC_PREV_DIST(9)
   WD_TC_PREV_DIST(10) WD_TC_PREV_DIST(11) WD_TC_PREV_DIST(12) WD_TC_PREV_DIST(13) WD_TC_PREV_DIST(14)
 #undef WD_TC_PREV_DIST
-  const float T = far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
+  const float T = (n >= (unsigned)(K + 2)) ? 1.15f * far3 : far * (1.15f * (float)(K + 3)) * __builtin_amdgcn_rcpf((float)n);
   return (n >= 5u) ? __float_as_uint(T) : 0x7f800000u;
 }
 
-// S: the L smallest keys among the candidates with d2 <= Tf, ascending; returns the (L+1)-th (one more id to remember)
-template <int L, int IDB, int U>
-__device__ __forceinline__ unsigned tc_chain_prefiltered(const float2 *cxy, float xi, float yi, int N, float Tf, int pad_idx,
-                                                         unsigned (&S)[L]) {
-  constexpr unsigned IDM = (1u << IDB) - 1u;
-  unsigned extra = 0xffffffffu;
-#pragma unroll
-  for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
-#define WD_TC_MASK_PUSH(m, d2v) \
-  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2v), "v"(Tf) : "vcc")
+// ---- CELL-SORTED packing (round 6; replicas of more than 128 agents while the prefiltered search is on).  The agents in the
+// game are packed by grid cell (C x C cells over the arena, row-major; a counting sort through LDS atomics, tc_fast.h) instead
+// of by id, so the 64 searchers of a wavefront are neighbours in space and pass 1 of the prefiltered search runs over the
+// cell rows around them only: ~300 instead of 1005 candidates at 1005 agents (experiments/offline/knn_cell_sort_sim.py).
+// Exactness costs nothing new: a candidate OUTSIDE the 3 x 3 cell block of a searcher is farther than the distance from the
+// searcher to the block's border, so the radius handed to the prefilter is min(hint radius, that distance squared) -- such a
+// candidate would have failed pass 1's compare anyway, the search is the search over ALL candidates with that radius, and
+// the `held` check of the caller (the K-th found lies two key buckets inside the radius) covers it.  Ties are settled by
+// agent id through the packed-index -> id table (tc_tie_order<true>), so the packing order is free; within a cell it is the
+// order of the LDS atomics, which varies from run to run and changes nothing that leaves the kernel but the look-ahead
+// ids remembered in `knn_prev` (a hint).
+// Side of the grid for `n_live` agents in the game (0: pack by id, one range): cells of at least 2.2 x the expected distance
+// to the K-th neighbour at uniform density (r_K = length x sqrt(K / (pi n))), at most 8 x 8 (one counter per lane).
+__device__ __forceinline__ int tc_cell_grid(int n_live, int K) {
+  const int c = (int)sqrtf((float)n_live * (3.14159265f / (2.2f * 2.2f)) / (float)K);
+  return c >= 4 ? min(c, 8) : 0;
+}
+// (positions are clipped to [0, length]: the products are in [0, C])
+__device__ __forceinline__ int2 tc_cell_xy(float x, float y, float inv, int C) {
+  return make_int2(min(C - 1, (int)(x * inv)), min(C - 1, (int)(y * inv)));
+}
+// squared distance from (x, y) in cell (cx, cy) to the border of its 3 x 3 block, less a margin of 1/1024 cell (the cell
+// index comes from a rounded product, the border from another: both are within a few ulps of the arena's length of the
+// exact values, a thousand times less than the margin); the arena's own border does not count.  Bits; 0x7f800000 = none.
+__device__ __forceinline__ unsigned tc_cell_cover2(float x, float y, int2 c, float len, int C) {
+  float cover = __builtin_inff();
+  if (c.x > 0) cover = fminf(cover, x - (float)(c.x - 1) * len);
+  if (c.x < C - 1) cover = fminf(cover, (float)(c.x + 2) * len - x);
+  if (c.y > 0) cover = fminf(cover, y - (float)(c.y - 1) * len);
+  if (c.y < C - 1) cover = fminf(cover, (float)(c.y + 2) * len - y);
+  cover = fmaxf(cover - len * (1.0f / 1024.0f), 0.0f);
+  return __float_as_uint(cover * cover);
+}
+
+// The prefiltered search keeps, per searcher lane, a LIST in the wavefront's staging buffer (dead between the hint read and
+// the row gather): the non-empty 32-candidate mask words of pass 1 with the index of the candidate on bit 0, rows of 64
+// lanes.  Pass 2 then pops ACROSS words: a lane that has used up a word moves on to its next one in the same trip, so a
+// round of pass 2 takes as many trips as the fullest lane has candidates in the whole list (~10 per 256 candidates) --
+// word by word (rounds 4-5) it took the sum over the words of the fullest lane PER WORD: 80 - 120 trips per search, and more
+// the closer the wavefront's searchers sit together (profiles/r06_phase_cells_*.txt).  WD_TC_LIST_CAP words per round.
+#define WD_TC_LIST_CAP 8
+#define WD_TC_LIST_DWORDS ((WD_TC_LIST_CAP + 1) * (64 + 32))  // masks (u32) + bit-0 indices (u16), one spare row each
+struct TcPreList {
+  unsigned *masks;        // [CAP + 1][64], this lane's column
+  unsigned short *tops;   // [CAP + 1][64], this lane's column
+};
+__device__ __forceinline__ TcPreList tc_pre_list(float *stage, int lane) {
+  TcPreList pl;
+  pl.masks = (unsigned *)stage + lane;
+  pl.tops = (unsigned short *)((unsigned *)stage + (WD_TC_LIST_CAP + 1) * 64) + lane;
+  return pl;
+}
+
+// ---- pass 1 over the candidates [j0, j1) (j0 a multiple of 4; j1 a multiple of 4 or the number of candidates; at most
+// CAP - (words listed since the last round) words): squared distance and ONE compare against the radius per candidate,
+// shifted into the word's mask (candidate b of a word of nb ends on bit nb - 1 - b); every word is written to slot `cnt` of
+// the lane's list, and only a non-empty one keeps the slot.
+__device__ __forceinline__ void tc_pre_pass1(const float2 *cxy, float xi, float yi, int j0, int j1, float Tf, const TcPreList &pl,
+                                             int &cnt) {
+  // The compare is a subtraction: the sign of Tf - d2 is set iff d2 > Tf (d2 == Tf gives +0, a pad position -inf), and
+  // v_alignbit shifts it into the word -- two full-rate instructions where v_cmp + v_addc (carry in and out) take ~3 cycles
+  // each on gfx950 (experiments/README.md).  The word collects the "outside" bits and is inverted at the end.
+#define WD_TC_MASK_PUSH(m, d2v) (m) = __builtin_amdgcn_alignbit((m), __float_as_uint(Tf - (d2v)), 31)
 #define WD_TC_MASK_PUSH4(m, grp)                                       \
   do {                                                                 \
     float d_[4];                                                       \
@@ -509,91 +570,81 @@ __device__ __forceinline__ unsigned tc_chain_prefiltered(const float2 *cxy, floa
     WD_TC_MASK_PUSH(m, d_[0]); WD_TC_MASK_PUSH(m, d_[1]);              \
     WD_TC_MASK_PUSH(m, d_[2]); WD_TC_MASK_PUSH(m, d_[3]);              \
   } while (0)
-#define WD_TC_POP2(ix, px)                                                                     \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
-    const bool have_ = (mw != 0u);                                                             \
-    ix[u] = have_ ? (unsigned)(top - (__ffs(mw) - 1)) : (unsigned)pad_idx;                     \
-    mw &= mw - 1u;                                                                             \
-    px[u] = cxy[ix[u]];                                                                        \
-  }
-#ifdef WD_TC_PROBES
-  int probe_trips = 0;
-#endif
-  for (int c0 = 0; c0 < N; c0 += 128) {  // wave-uniform
-    // ---- pass 1 of this chunk: candidate b of word w (candidates c0 + 32 w .. + nb - 1) ends on bit nb - 1 - b
-    unsigned mask[4] = {0u, 0u, 0u, 0u};
-    TcP4 ga = tc_load4(cxy, c0), gb;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int j0 = c0 + 32 * w;
-      if (j0 < N) {  // wave-uniform
-        const int nb = min(32, N - j0);
-        unsigned mu = 0u;
-        int b = 0;
-        for (; b + 8 <= nb; b += 8) {  // two groups of four per trip, ping-pong
-          gb = tc_load4(cxy, j0 + b + 4);
-          WD_TC_MASK_PUSH4(mu, ga);
-          ga = tc_load4(cxy, j0 + b + 8);  // (at most 8 entries past the last candidate: padding)
-          WD_TC_MASK_PUSH4(mu, gb);
-        }
-        if (b + 4 <= nb) {
-          gb = tc_load4(cxy, j0 + b + 4);
-          WD_TC_MASK_PUSH4(mu, ga);
-          ga = gb;
-          b += 4;
-        }
-        for (; b < nb; ++b) {  // (only the last word can have a remainder)
-          const float2 pj = cxy[j0 + b];
-          const float dx = xi - pj.x, dy = yi - pj.y;
-          const float d2 = dx * dx + dy * dy;
-          WD_TC_MASK_PUSH(mu, d2);
-        }
-        mask[w] = mu;
-      }
+  TcP4 ga = tc_load4(cxy, j0), gb;
+  for (int jw = j0; jw < j1; jw += 32) {  // wave-uniform
+    const int nb = min(32, j1 - jw);
+    unsigned mo = 0xffffffffu;  // bit set: outside the radius (or no candidate)
+    int b = 0;
+    for (; b + 8 <= nb; b += 8) {  // two groups of four per trip, ping-pong
+      gb = tc_load4(cxy, jw + b + 4);
+      WD_TC_MASK_PUSH4(mo, ga);
+      ga = tc_load4(cxy, jw + b + 8);  // (at most 8 entries past the last candidate: padding; else the next word's first group)
+      WD_TC_MASK_PUSH4(mo, gb);
     }
-    // ---- pass 2 of this chunk
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int j0 = c0 + 32 * w;
-      if (j0 < N) {  // wave-uniform
-        const int top = j0 + min(32, N - j0) - 1;  // the candidate on bit 0
-        unsigned mw = mask[w];
-        unsigned idx[U], idn[U];
-        float2 pj[U], pn[U];
-        bool more = __ballot(mw != 0u) != 0ull;  // wave-uniform: as many trips as the fullest lane needs
-        if (more) {
-          WD_TC_POP2(idn, pn);
-          while (more) {
-#ifdef WD_TC_PROBES
-            ++probe_trips;
-#endif
-#pragma unroll
-            for (int u = 0; u < U; ++u) { idx[u] = idn[u]; pj[u] = pn[u]; }
-            more = __ballot(mw != 0u) != 0ull;
-            if (more) { WD_TC_POP2(idn, pn); }
-            asm volatile("" ::: "memory");  // (keeps the reads above the work below)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const float dx = xi - pj[u].x, dy = yi - pj[u].y;
-              const float d2 = dx * dx + dy * dy;
-              const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx[u];
-              extra = tc_umed3(S[L - 1], extra, key_);
-#pragma unroll
-              for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
-              S[0] = min(S[0], key_);
-            }
-          }
-        }
-      }
+    if (b + 4 <= nb) {
+      gb = tc_load4(cxy, jw + b + 4);
+      WD_TC_MASK_PUSH4(mo, ga);
+      ga = gb;
+      b += 4;
     }
+    for (; b < nb; ++b) {  // (only the last word of the candidates can have a remainder)
+      const float2 pj = cxy[jw + b];
+      const float dx = xi - pj.x, dy = yi - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      WD_TC_MASK_PUSH(mo, d2);
+    }
+    const unsigned mu = ~mo;  // (bits nb and up were shifted in from the all-ones start: clear)
+    pl.masks[cnt * 64] = mu;
+    pl.tops[cnt * 64] = (unsigned short)(jw + nb - 1);
+    cnt += (mu != 0u) ? 1 : 0;
   }
-#ifdef WD_TC_PROBES
-  WD_TC_PROBE_VAL(18, probe_trips);
-#endif
-#undef WD_TC_POP2
 #undef WD_TC_MASK_PUSH4
 #undef WD_TC_MASK_PUSH
-  return extra;
+}
+
+// ---- pass 2 over the lists: the listed candidates go through the chain.  S = the L smallest keys so far, ascending;
+// `extra` = the (L+1)-th (one more id to remember); both start at 0xffffffff.  A lane without a candidate left inserts the pad
+// position (+inf).  The next trip's candidate is popped and its position read before the current one goes through the chain.
+template <int L, int IDB>
+__device__ __forceinline__ void tc_pre_pass2(const float2 *cxy, float xi, float yi, int pad_idx, const TcPreList &pl, int cnt,
+                                             unsigned (&S)[L], unsigned &extra, int &probe_trips) {
+  constexpr unsigned IDM = (1u << IDB) - 1u;
+  unsigned cur = (cnt > 0) ? pl.masks[0] : 0u, nxt = pl.masks[64];
+  int top = pl.tops[0], ntop = pl.tops[64], pos1 = 1;
+#define WD_TC_POP(ix, px)                                                                      \
+  do {                                                                                         \
+    const bool have_ = (cur != 0u);                                                            \
+    ix = have_ ? (unsigned)(top - (__ffs(cur) - 1)) : (unsigned)pad_idx;                       \
+    cur &= cur - 1u;                                                                           \
+    px = cxy[ix];                                                                              \
+    const bool take_ = (cur == 0u) && (pos1 < cnt);  /* on to the lane's next word */          \
+    cur = take_ ? nxt : cur;                                                                   \
+    top = take_ ? ntop : top;                                                                  \
+    pos1 += take_ ? 1 : 0;                                                                     \
+    nxt = pl.masks[pos1 * 64];   /* (row pos1 <= CAP: the spare row is never taken) */         \
+    ntop = pl.tops[pos1 * 64];                                                                 \
+  } while (0)
+  bool more = __ballot(cur != 0u) != 0ull;  // wave-uniform: as many trips as the fullest lane needs
+  if (more) {
+    unsigned idx, idn;
+    float2 pj, pn;
+    WD_TC_POP(idn, pn);
+    while (more) {
+      ++probe_trips;
+      idx = idn; pj = pn;
+      more = __ballot(cur != 0u) != 0ull;
+      if (more) { WD_TC_POP(idn, pn); }
+      asm volatile("" ::: "memory");  // (keeps the reads above the work below)
+      const float dx = xi - pj.x, dy = yi - pj.y;
+      const float d2 = dx * dx + dy * dy;
+      const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx;
+      extra = tc_umed3(S[L - 1], extra, key_);
+#pragma unroll
+      for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
+      S[0] = min(S[0], key_);
+    }
+  }
+#undef WD_TC_POP
 }
 
 // ---- exact resolution for ONE searcher by the WHOLE wavefront (replicas of more than 128 agents; the K-pass scan

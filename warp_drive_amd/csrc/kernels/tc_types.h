@@ -108,6 +108,8 @@ struct TcTables {
   int *tstep, *nrun; // [epb]
   float *tfrac;      // [epb] float(t) / episode_length
   int *doneflag;     // [epb] replica finished on this tick (fused tick only)
+  int *cell_cnt;     // [64] agents in the game per grid cell (cell-sorted search of replicas of more than 128 agents, tc_fast.h;
+                     // behind everything else: the host adds the bytes for those replicas only, envs/tag_continuous.py lds_bytes)
 };
 
 __device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, int N) {
@@ -121,7 +123,8 @@ __device__ __forceinline__ TcTables tc_carve_tables(unsigned char *p, int epb, i
   t.tstep = (int *)(p + off); off += 4 * epb;
   t.nrun = (int *)(p + off); off += 4 * epb;
   t.tfrac = (float *)(p + off); off += 4 * epb;
-  t.doneflag = (int *)(p + off);
+  t.doneflag = (int *)(p + off); off += 4 * epb;
+  t.cell_cnt = (int *)(p + off);
   return t;
 }
 

@@ -376,6 +376,8 @@ class TagContinuous(CUDAEnvironmentContext):
             n_waves = ((A if threads is None else threads) + 63) // 64
             stage_rows = max(1, min(64, (self.STAGE_TARGET_BYTES // 2 if n_waves > 4 else self.STAGE_TARGET_BYTES) // (4 * F)))
             stage_dwords = align16(4 * stage_rows * F) // 4 + 4 + 16   # row images + the list of live rows
+            if epb == 1 and N > 128:  # + room for the prefiltered search's candidate lists (WD_TC_LIST_DWORDS, tc_knn.h)
+                stage_dwords = max(stage_dwords, 864)
             area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
             if epb == 1:  # packed positions of the agents in the game + the packed-index -> id table
                 area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(2 * (N + 1))
@@ -386,7 +388,10 @@ class TagContinuous(CUDAEnvironmentContext):
             # than 256 agents sample the heads one after the other from ONE slab (tc_one_slab in the kernel file)
             slabs = (align16(4 * A * len(self.acceleration_actions)), align16(4 * A * len(self.turn_actions)))
             area = max(area, max(slabs) if N > 256 else sum(slabs))
-        return align16(area) + 4 * N + 4 * (2 * 64 + 32) + 4 * 4 * epb + 16   # + tagger list, action tables, per-wavefront counts, per-replica scalars
+        tables = 4 * N + 4 * (2 * 64 + 32) + 4 * 4 * epb + 16   # tagger list, action tables, per-wavefront counts, per-replica scalars
+        if self._fast_path() and N > 128:  # + the 64 cell counters of the cell-sorted neighbour search (TcTables::cell_cnt)
+            tables += 4 * 64
+        return align16(area) + tables
 
     def _geometry(self):
         """(replicas per block, block, grid): whole replicas packed into blocks of at most 256 threads
