@@ -138,7 +138,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         if constexpr (PRE) {
           if (cells_C != 0) {  // its packed place is known after the barrier (counting sort)
             const int2 c = tc_cell_xy(m.x, m.y, cell_inv, cells_C);
-            my_cell = c.y * cells_C + c.x;
+            my_cell = tc_cell_place(c, cells_C);
             my_cell_slot = atomicAdd(&tb.cell_cnt[my_cell], 1);
             by_cell = true;
           }
@@ -263,8 +263,8 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
 #pragma unroll
         for (int k = 0; k < L; ++k) S[k] = 0xffffffffu;
         // Packed by id: ONE run, every candidate.  Packed by cell: the wavefront's searchers hold consecutive packed places,
-        // i.e. the cells (x_lo, y_lo) .. (x_hi, y_hi) in row-major order; per cell row r, the cells within one column of any
-        // of them in the rows r - 1 .. r + 1 are one run of packed places (the hull of the columns).  Runs are taken in
+        // i.e. the cells (x_lo, y_lo) .. (x_hi, y_hi) of the serpentine sweep; per cell row r, the cells within one column of
+        // any of them in the rows r - 1 .. r + 1 are one run of packed places (the hull of the columns).  Runs are taken in
         // ascending order, widened to multiples of 4 places, never overlapping (a candidate must not enter the chain
         // twice) and joined where they touch.  All of it is scalar work; pass 1 and pass 2 have ONE call site each:
         // pass 1 lists up to WD_TC_LIST_CAP words of candidates (from one run or several), pass 2 empties the lists.
@@ -291,12 +291,19 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
               while (!flush && r <= r_end) {
                 int lo = C, hi = -1;
                 for (int yy = max(y_lo, r - 1); yy <= min(y_hi, r + 1); ++yy) {
-                  lo = min(lo, yy == y_lo ? x_lo : 0);
-                  hi = max(hi, yy == y_hi ? x_hi : C - 1);
+                  // the columns of cell row yy that hold searchers of this wavefront: the sweep runs left to right in even
+                  // rows, right to left in odd ones; it enters the wavefront at (x_lo, y_lo) and leaves it at (x_hi, y_hi)
+                  const bool fwd = (yy & 1) == 0;
+                  const int from = (yy == y_lo) ? x_lo : (fwd ? 0 : C - 1), to = (yy == y_hi) ? x_hi : (fwd ? C - 1 : 0);
+                  lo = min(lo, min(from, to));
+                  hi = max(hi, max(from, to));
                 }
-                const int first_cell = r * C + max(0, lo - 1), last_cell = r * C + min(C - 1, hi + 1);
+                lo = max(0, lo - 1);
+                hi = min(C - 1, hi + 1);
+                // (an odd row's cells are packed in descending column order)
+                const int first_cell = r * C + ((r & 1) ? C - 1 - hi : lo), last_cell = r * C + ((r & 1) ? C - 1 - lo : hi);
                 ++r;
-                if (hi < 0) continue;
+                if (hi < lo) continue;
                 const int b = first_cell == 0 ? 0 : __builtin_amdgcn_readlane(cell_incl, max(first_cell, 1) - 1);
                 const int e = __builtin_amdgcn_readlane(cell_incl, last_cell);
                 const int j0 = max(run1, b & ~3), j1 = min(n_cand, (e + 3) & ~3);

@@ -498,7 +498,7 @@ __device__ __forceinline__ unsigned tc_knn_bound16(const float2 *xy_by_id, int p
 }
 
 // ---- CELL-SORTED packing (round 6; replicas of more than 128 agents while the prefiltered search is on).  The agents in the
-// game are packed by grid cell (C x C cells over the arena, row-major; a counting sort through LDS atomics, tc_fast.h) instead
+// game are packed by grid cell (C x C cells over the arena, a serpentine sweep; a counting sort through LDS atomics, tc_fast.h) instead
 // of by id, so the 64 searchers of a wavefront are neighbours in space and pass 1 of the prefiltered search runs over the
 // cell rows around them only: ~300 instead of 1005 candidates at 1005 agents (experiments/offline/knn_cell_sort_sim.py).
 // Exactness costs nothing new: a candidate OUTSIDE the 3 x 3 cell block of a searcher is farther than the distance from the
@@ -518,6 +518,11 @@ __device__ __forceinline__ int tc_cell_grid(int n_live, int K) {
 __device__ __forceinline__ int2 tc_cell_xy(float x, float y, float inv, int C) {
   return make_int2(min(C - 1, (int)(x * inv)), min(C - 1, (int)(y * inv)));
 }
+// place of a cell in the packing order: a SERPENTINE sweep (even rows left to right, odd rows right to left), so that the
+// cells of 64 consecutive packed agents stay neighbours where the sweep changes rows -- in row-major order a wavefront
+// that wraps holds the end of one row and the start of the next, and its candidate runs are two whole cell rows
+// (258 instead of 305 candidates per wavefront at 1005 agents, experiments/offline/knn_cell_sort_sim.py)
+__device__ __forceinline__ int tc_cell_place(int2 c, int C) { return c.y * C + ((c.y & 1) ? C - 1 - c.x : c.x); }
 // squared distance from (x, y) in cell (cx, cy) to the border of its 3 x 3 block, less a margin of 1/1024 cell (the cell
 // index comes from a rounded product, the border from another: both are within a few ulps of the arena's length of the
 // exact values, a thousand times less than the margin); the arena's own border does not count.  Bits; 0x7f800000 = none.
@@ -534,10 +539,10 @@ __device__ __forceinline__ unsigned tc_cell_cover2(float x, float y, int2 c, flo
 // The prefiltered search keeps, per searcher lane, a LIST in the wavefront's staging buffer (dead between the hint read and
 // the row gather): the non-empty 32-candidate mask words of pass 1 with the index of the candidate on bit 0, rows of 64
 // lanes.  Pass 2 then pops ACROSS words: a lane that has used up a word moves on to its next one in the same trip, so a
-// round of pass 2 takes as many trips as the fullest lane has candidates in the whole list (~10 per 256 candidates) --
+// round of pass 2 takes as many trips as the fullest lane has candidates in the whole list (~40 for the ~300 candidates of a wavefront) --
 // word by word (rounds 4-5) it took the sum over the words of the fullest lane PER WORD: 80 - 120 trips per search, and more
 // the closer the wavefront's searchers sit together (profiles/r06_phase_cells_*.txt).  WD_TC_LIST_CAP words per round.
-#define WD_TC_LIST_CAP 8
+#define WD_TC_LIST_CAP 11  // (a 1024-agent replica with K = 12 and sixteen such buffers still fits the 160 KB of a workgroup)
 #define WD_TC_LIST_DWORDS ((WD_TC_LIST_CAP + 1) * (64 + 32))  // masks (u32) + bit-0 indices (u16), one spare row each
 struct TcPreList {
   unsigned *masks;        // [CAP + 1][64], this lane's column

@@ -117,8 +117,8 @@ __device__ __forceinline__ TcFastLds tc_carve_fast(unsigned char *p0, int epb, i
   l.ids = (unsigned short *)(p0 + off); off = tc_align16(off + 2 * A * K);
   l.stage_dwords = (int)(tc_align16((size_t)4 * tc_stage_rows(F, n_waves) * F) / 4) + 4 + 16;  // + the list of live rows (64 bytes)
   // replicas of more than 128 agents: the buffer also holds the prefiltered search's hints (8 dwords per lane) and, after
-  // them, its candidate lists (tc_knn.h WD_TC_LIST_DWORDS = 864; the host adds the same, envs/tag_continuous.py lds_bytes)
-  if (compact && N > 128) l.stage_dwords = max(l.stage_dwords, 864);
+  // them, its candidate lists (tc_knn.h WD_TC_LIST_DWORDS = 1152; the host adds the same, envs/tag_continuous.py lds_bytes)
+  if (compact && N > 128) l.stage_dwords = max(l.stage_dwords, 1152);
   l.stage = (float *)(p0 + off); off += (size_t)4 * l.stage_dwords * n_waves;
   off = tc_align16(off > min_area_bytes ? off : min_area_bytes);
   l.tb = tc_carve_tables(p0 + off, epb, N);

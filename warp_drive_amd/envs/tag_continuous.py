@@ -377,7 +377,7 @@ class TagContinuous(CUDAEnvironmentContext):
             stage_rows = max(1, min(64, (self.STAGE_TARGET_BYTES // 2 if n_waves > 4 else self.STAGE_TARGET_BYTES) // (4 * F)))
             stage_dwords = align16(4 * stage_rows * F) // 4 + 4 + 16   # row images + the list of live rows
             if epb == 1 and N > 128:  # + room for the prefiltered search's candidate lists (WD_TC_LIST_DWORDS, tc_knn.h)
-                stage_dwords = max(stage_dwords, 864)
+                stage_dwords = max(stage_dwords, 1152)
             area = 32 * A + 8 * epb * ((N + 3) // 4 * 4 + 8) + 4 * A + 4 * A   # features, padded positions, 2 flag arrays
             if epb == 1:  # packed positions of the agents in the game + the packed-index -> id table
                 area = align16(area) + 8 * ((N + 3) // 4 * 4 + 8) + align16(2 * (N + 1))
