@@ -324,7 +324,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
             words += (j_stop - j + 31) >> 5;
             j = j_stop;
           }
-          if (words != 0) tc_pre_pass2<L, IDB>(sxy, sx, sy, n_cand, pl, listed, S, extra, probe_trips);
+          if (words != 0) tc_pre_pass2<L, IDB>(sxy, sx, sy, pl, listed, S, extra, probe_trips);
           listed = 0;
           words = 0;
         }

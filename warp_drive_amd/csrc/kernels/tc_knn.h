@@ -608,48 +608,44 @@ __device__ __forceinline__ void tc_pre_pass1(const float2 *cxy, float xi, float 
 }
 
 // ---- pass 2 over the lists: the listed candidates go through the chain.  S = the L smallest keys so far, ascending;
-// `extra` = the (L+1)-th (one more id to remember); both start at 0xffffffff.  A lane without a candidate left inserts the pad
-// position (+inf).  The next trip's candidate is popped and its position read before the current one goes through the chain.
+// `extra` = the (L+1)-th (one more id to remember); both start at 0xffffffff.  A plain divergent loop: a lane leaves it when
+// its list is empty (the wavefront makes as many trips as its fullest lane has candidates), and moving on to the lane's next
+// word is a branch, not a run of selects -- the search is VALU-bound at four wavefronts per SIMD, the scalar unit and the
+// other wavefronts cover the branches and the LDS round trips (round 6: ~30 instead of ~40 vector instructions per trip
+// against the branch-free, software-pipelined form with a pad candidate for lanes that ran out).
 template <int L, int IDB>
-__device__ __forceinline__ void tc_pre_pass2(const float2 *cxy, float xi, float yi, int pad_idx, const TcPreList &pl, int cnt,
+__device__ __forceinline__ void tc_pre_pass2(const float2 *cxy, float xi, float yi, const TcPreList &pl, int cnt,
                                              unsigned (&S)[L], unsigned &extra, int &probe_trips) {
   constexpr unsigned IDM = (1u << IDB) - 1u;
-  unsigned cur = (cnt > 0) ? pl.masks[0] : 0u, nxt = pl.masks[64];
-  int top = pl.tops[0], ntop = pl.tops[64], pos1 = 1;
-#define WD_TC_POP(ix, px)                                                                      \
-  do {                                                                                         \
-    const bool have_ = (cur != 0u);                                                            \
-    ix = have_ ? (unsigned)(top - (__ffs(cur) - 1)) : (unsigned)pad_idx;                       \
-    cur &= cur - 1u;                                                                           \
-    px = cxy[ix];                                                                              \
-    const bool take_ = (cur == 0u) && (pos1 < cnt);  /* on to the lane's next word */          \
-    cur = take_ ? nxt : cur;                                                                   \
-    top = take_ ? ntop : top;                                                                  \
-    pos1 += take_ ? 1 : 0;                                                                     \
-    nxt = pl.masks[pos1 * 64];   /* (row pos1 <= CAP: the spare row is never taken) */         \
-    ntop = pl.tops[pos1 * 64];                                                                 \
-  } while (0)
-  bool more = __ballot(cur != 0u) != 0ull;  // wave-uniform: as many trips as the fullest lane needs
-  if (more) {
-    unsigned idx, idn;
-    float2 pj, pn;
-    WD_TC_POP(idn, pn);
-    while (more) {
-      ++probe_trips;
-      idx = idn; pj = pn;
-      more = __ballot(cur != 0u) != 0ull;
-      if (more) { WD_TC_POP(idn, pn); }
-      asm volatile("" ::: "memory");  // (keeps the reads above the work below)
-      const float dx = xi - pj.x, dy = yi - pj.y;
-      const float d2 = dx * dx + dy * dy;
-      const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx;
-      extra = tc_umed3(S[L - 1], extra, key_);
-#pragma unroll
-      for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
-      S[0] = min(S[0], key_);
+  unsigned cur = (cnt > 0) ? pl.masks[0] : 0u;
+  int top = pl.tops[0], pos1 = 1;
+#ifdef WD_TC_PROBES
+  int my_trips = 0;
+#endif
+  while (cur != 0u) {
+#ifdef WD_TC_PROBES
+    ++my_trips;
+#endif
+    const unsigned idx = (unsigned)(top - (__ffs(cur) - 1));
+    cur &= cur - 1u;
+    const float2 pj = cxy[idx];
+    if (cur == 0u && pos1 < cnt) {  // on to the lane's next word
+      cur = pl.masks[pos1 * 64];
+      top = pl.tops[pos1 * 64];
+      ++pos1;
     }
+    const float dx = xi - pj.x, dy = yi - pj.y;
+    const float d2 = dx * dx + dy * dy;
+    const unsigned key_ = (__float_as_uint(d2) & ~IDM) | idx;
+    extra = tc_umed3(S[L - 1], extra, key_);
+#pragma unroll
+    for (int k = L - 1; k >= 1; --k) S[k] = tc_umed3(S[k - 1], S[k], key_);
+    S[0] = min(S[0], key_);
   }
-#undef WD_TC_POP
+#ifdef WD_TC_PROBES
+  for (int o = 32; o > 0; o >>= 1) my_trips = max(my_trips, __shfl_xor(my_trips, o, 64));  // the wavefront's trips = its fullest lane's
+  probe_trips += my_trips;
+#endif
 }
 
 // ---- exact resolution for ONE searcher by the WHOLE wavefront (replicas of more than 128 agents; the K-pass scan
