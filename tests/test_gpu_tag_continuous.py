@@ -747,6 +747,49 @@ def test_cell_sorted_search_on_a_lattice_of_exact_ties(side, spacing, kernel):
     assert (srt[:, 9] == srt[:, 10]).mean() > 0.8
 
 
+@pytest.mark.parametrize("n_runners,kernel", [(996, "HipTagContinuousStep_K10_N1024"), (400, "HipTagContinuousStep_K10_N512")])
+def test_cell_sorted_search_with_a_crowd_in_one_corner(n_runners, kernel):
+    """The cell-sorted search sizes its cells for a uniform crowd; here 70 % of the agents stand inside a blob of radius
+    ~1 in one corner of a 20 x 20 arena (one or two cells hold most of the replica, a searcher's 3 x 3 block covers
+    everybody it can see) and the rest are spread thinly (their K-th neighbour lies far outside their cell block: the
+    radius check fails and the wavefront repeats with the full chain).  The agents drift with their reset speeds for 6
+    ticks; every tick against the oracle (state, observations, nearest_neighbor_ids)."""
+    from tests.hip_harness import pull, push_actions
+
+    cfg = dict(num_taggers=4, num_runners=n_runners, grid_length=20.0, episode_length=30, seed=3,
+               max_acceleration=0.1, min_acceleration=-0.1, num_acceleration_levels=4, num_turn_levels=4, max_speed=0.3,
+               use_full_observation=False, num_other_agents_observed=10, tagging_distance=1e-5,
+               runner_exits_game_after_tagged=True)
+    E = 2
+    w = _mk(cfg, E)
+    assert w.env.resolve_step_function_name("HipTagContinuousStep") == kernel
+    orc = TagContinuousOracle(num_envs=E, **cfg)
+    N = orc.N
+    f32 = np.float32
+    rng = np.random.default_rng(n_runners)
+    xs, ys = np.zeros((E, N), f32), np.zeros((E, N), f32)
+    for e in range(E):
+        crowd = rng.random(N) < 0.7
+        cx, cy = (2.0, 2.5) if e == 0 else (19.0, 18.5)  # (the second replica's crowd leans on two arena walls)
+        xs[e] = np.where(crowd, np.clip(cx + 0.5 * rng.standard_normal(N), 0.0, 20.0), 20.0 * rng.random(N)).astype(f32)
+        ys[e] = np.where(crowd, np.clip(cy + 0.5 * rng.standard_normal(N), 0.0, 20.0), 20.0 * rng.random(N)).astype(f32)
+    state = dict(loc_x=xs, loc_y=ys, speed=(0.2 * rng.random((E, N))).astype(f32),
+                 direction=(6.28 * rng.random((E, N))).astype(f32), acceleration=np.zeros((E, N), f32))
+    orc.set_state(**state)
+    _push_state(w, **state)
+    stats = {"near_tie_rows": 0, "rows": 0}
+    na, nt = len(orc.acceleration_actions), len(orc.turn_actions)
+    act_rng = np.random.RandomState(5)
+    for t in range(6):
+        a = np.stack([act_rng.randint(0, na, size=(E, N)), act_rng.randint(0, nt, size=(E, N))], axis=2)
+        push_actions(w, a)
+        w.step_all_envs()
+        orc.step(a)
+        _compare(w, orc, f"t={t}", stats)
+    assert stats["near_tie_rows"] <= 2, stats
+    assert (pull(w, "still_in_the_game") == 1).all()
+
+
 @pytest.mark.parametrize("n_runners,K,full_obs", [(146, 8, False), (146, 8, True), (300, 10, False), (500, 10, False),
                                                   (525, 5, False), (1020, 3, False), (1000, 10, False), (700, 16, False),
                                                   (600, 20, False)])
