@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence in ONE call on the GPU box (~8 min): output under gpurun_out/profiles/, copy what is to be judged into
+# Round evidence (rounds 5 and 6) in ONE call on the GPU box (~8 min): output under gpurun_out/profiles/, copy what is to be judged into
 # profiles/.  Every profiler run sits under `timeout` (a rocprofv3 that does not return otherwise eats the lease).
 TAG=${1:-r05}
 cd "$(dirname "$0")/.."
