@@ -509,7 +509,10 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     // row*F + c*K + k of the chunk image; then the time column; then the chunk leaves as one run.
     // A chunk holds at most 192 items (tc_stage_rows), i.e. at most 3 per lane; their (row, slot)
     // split is the same for every chunk and is worked out once.
-    const int R = tc_stage_rows(F, n_waves);
+    int R = tc_stage_rows(F, n_waves);
+    if constexpr (IDB != 7) {  // replicas of more than 128 agents: the buffer is at least the search's lists -- fill it
+      R = max(R, min(min(64, (l.stage_dwords - 20) / F), 192 / K));
+    }
     constexpr int U = 3;
     int rr[U], so[U];
 #pragma unroll
