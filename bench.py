@@ -203,6 +203,8 @@ def main():
                          "(2000 replicas x 250 ticks, both policies, the real one-bucket gradient all-reduce) after one warm-up "
                          "iteration -- rollout_ms, update_ms, allreduce_us measured inside the iteration, end-to-end env-steps/s, "
                          "collectives per iteration, parameter checksum per rank.  auto = when --gpus > 1 (tag_continuous only)")
+    ap.add_argument("--trainer-timeout", type=float, default=300.0,
+                    help="seconds after which the trainer leg is abandoned (the kernel line is printed without it)")
     ap.add_argument("--trainer-num-envs", type=int, default=2000, help="replicas per rank of the trainer leg")
     ap.add_argument("--trainer-ticks", type=int, default=250, help="ticks per training iteration of the trainer leg")
     ap.add_argument("--unfused", action="store_true",
@@ -381,23 +383,7 @@ def main():
     kern_us = (sum(win_us) + sum(win_us2)) / (len(win_us) + len(win_us2))
     kern_n = (len(win_us) + len(win_us2)) * WIN
 
-    # BASELINE configs[3] is a TRAINING configuration (PPO + the gradient all-reduce over RCCL): at N > 1 the line also
-    # carries one training iteration timed from the inside, on every rank (collectives inside: all ranks take part)
-    trainer_leg = None
-    if is_tc and (args.trainer_leg == "on" or (args.trainer_leg == "auto" and world > 1)):
-        from warp_drive_amd.training.bench_iteration import run_configs3_iteration
-
-        try:
-            trainer_leg = run_configs3_iteration(args.trainer_num_envs, args.trainer_ticks, warmup_iterations=1)
-            trainer_leg["hardware_note"] = ("RCCL over xGMI" if world > 1 and os.environ.get("WD_DIST_BACKEND") in (None, "", "nccl")
-                                            else "single rank: no collective" if world == 1 else
-                                            f"backend {os.environ.get('WD_DIST_BACKEND')} (not RCCL)")
-        except Exception as err:  # the kernel line is the contract; a failed trainer leg must not lose it
-            import traceback
-
-            traceback.print_exc()
-            trainer_leg = {"failed": f"{type(err).__name__}: {err}"}
-
+    out = None
     if rank == 0:
         N = w.n_agents
         if args.workload == "tag_continuous":
@@ -511,8 +497,6 @@ def main():
             "roofline_valu": valu_roofline(engine.step_kernel_name, E, bool(args.full_obs), kern_us)
             if is_tc else None,
         }
-        if trainer_leg is not None:
-            out["trainer"] = trainer_leg
         if is_tc and args.mode == "plan" and kern_us > 0:
             # The cost of a TagContinuous tick falls along the episode (agents leave the game), so a `value` timed over a
             # window that is not a whole number of episodes is the rate of THAT window (the contract: exactly K timed
@@ -529,6 +513,44 @@ def main():
             except Exception as err:  # the baseline is reported context, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "env_steps/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {err}"}
+
+    # BASELINE configs[3] is a TRAINING configuration (PPO + the gradient all-reduce over RCCL): at N > 1 the line also
+    # carries one training iteration timed from the inside, on every rank (collectives inside: all ranks take part).
+    # The kernel line above is the contract and is complete by now: whatever the trainer leg does -- an exception (reported
+    # in the line; the ranks agree on it before they enter a collective, training/bench_iteration.py), or a rank that dies
+    # or hangs inside a collective (nobody can be called back from there) -- the line is printed and the job ends: a
+    # watchdog on every rank prints it (rank 0) and leaves after --trainer-timeout seconds.
+    if is_tc and (args.trainer_leg == "on" or (args.trainer_leg == "auto" and world > 1)):
+        import threading
+
+        from warp_drive_amd.training.bench_iteration import run_configs3_iteration
+
+        def give_up():
+            if rank == 0:
+                out["trainer"] = {"failed": f"no result after {args.trainer_timeout} s: a rank failed or a collective hung; "
+                                            "the kernel line above is unaffected"}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write(f"bench.py: rank {rank}: trainer leg abandoned after {args.trainer_timeout} s\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(float(args.trainer_timeout), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            trainer_leg = run_configs3_iteration(args.trainer_num_envs, args.trainer_ticks, warmup_iterations=1)
+            trainer_leg["hardware_note"] = ("RCCL over xGMI" if world > 1 and os.environ.get("WD_DIST_BACKEND") in (None, "", "nccl")
+                                            else "single rank: no collective" if world == 1 else
+                                            f"backend {os.environ.get('WD_DIST_BACKEND')} (not RCCL)")
+        except Exception as err:  # the kernel line is the contract; a failed trainer leg must not lose it
+            import traceback
+
+            traceback.print_exc()
+            trainer_leg = {"failed": f"{type(err).__name__}: {err}"}
+        watchdog.cancel()
+        if rank == 0:
+            out["trainer"] = trainer_leg
+    if rank == 0:
         print(json.dumps(out), flush=True)
     wdd.shutdown()
 

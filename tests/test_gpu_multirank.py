@@ -40,7 +40,9 @@ def test_bench_two_ranks_started_plainly():
 
     require_gpu()
     one = _bench([])
-    two = _bench(["--gpus", "2"])  # plain `python bench.py --gpus 2`: bench.py starts its own ranks
+    # plain `python bench.py --gpus 2`: bench.py starts its own ranks.  (The configs[3] trainer iteration that N > 1 adds to
+    # the line is the next test's, at a size two ranks can share one GPU with: 2 x 116 GB of stored activations do not fit.)
+    two = _bench(["--gpus", "2", "--trainer-leg", "off"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
     assert two["config"]["num_envs_per_gpu"] == 500
     assert two["config"]["sampler_seeds"] == [274880, 274881]  # seed + rank
@@ -75,6 +77,19 @@ def test_bench_line_carries_the_configs3_trainer_iteration():
     assert t["iteration_ms"] >= max(t["rollout_ms"], t["update_ms"]) > 0
     assert "gloo" in t["hardware_note"]
     assert set(t["update_plan"]) == {"runner", "tagger"}
+
+
+def test_bench_line_survives_a_trainer_leg_that_does_not_come_back():
+    """The kernel line is the driver's contract; the configs[3] trainer iteration rides along at N > 1.  If that leg does
+    not return -- a rank died inside a collective and the others wait for it for ever -- a watchdog on every rank prints
+    the line (rank 0) and ends the job with exit code 0.  Forced here with a timeout no iteration can meet."""
+    from tests.hip_harness import require_gpu
+
+    require_gpu()
+    for extra in (["--trainer-leg", "on"], ["--gpus", "2"]):
+        line = _bench(extra + ["--trainer-timeout", "0.5", "--trainer-num-envs", "60", "--trainer-ticks", "12"])
+        assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+        assert "failed" in line["trainer"] and "0.5 s" in line["trainer"]["failed"], line["trainer"]
 
 
 def test_train_two_ranks(tmp_path):

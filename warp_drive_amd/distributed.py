@@ -147,6 +147,12 @@ def sum_over_ranks(value):
     return float(t.item())
 
 
+def all_ranks_ok(ok):
+    """True iff `ok` on EVERY rank (one small collective): ranks agree on whether to go on before a step that contains
+    collectives -- a rank that failed alone would leave the others waiting in theirs"""
+    return min(gather_ints(1 if ok else 0)) == 1
+
+
 def gather_ints(value):
     """[value of rank 0, value of rank 1, ...] on every rank"""
     if not (dist.is_available() and dist.is_initialized()):

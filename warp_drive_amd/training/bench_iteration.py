@@ -38,7 +38,16 @@ def measure_training_iteration(trainer, warmup_iterations=1):
 
     bucket = trainer.grad_bucket
     for it in range(int(warmup_iterations)):
-        trainer._generate_rollout_batch()
+        # the rollout has no collective in it: a rank that cannot run it (memory) says so BEFORE anybody enters the update's
+        # all-reduce, and every rank leaves together
+        err = None
+        try:
+            trainer._generate_rollout_batch()
+            sync()
+        except Exception as e:  # noqa: BLE001 -- reported, and agreed on by all ranks
+            err = e
+        if not wdd.all_ranks_ok(err is None):
+            raise RuntimeError(f"warm-up rollout failed on {'this rank: ' + type(err).__name__ + ': ' + str(err) if err else 'another rank'}")
         trainer._update_model_params(it, False)
     sync()
     bucket.time_collectives = True
@@ -98,7 +107,17 @@ def run_configs3_iteration(num_envs=2000, ticks=250, warmup_iterations=1, result
     base = yaml.safe_load(open(train_script.os.path.join(train_script._CONFIGS, "tag_continuous.yaml")))
     ov["policy"] = {p: dict(cfg, algorithm="PPO") for p, cfg in base["policy"].items()}
     with tempfile.TemporaryDirectory() as tmp:
-        trainer = train_script.setup_trainer("tag_continuous", ov, results_dir=results_dir or tmp, verbose=False)
-        out = measure_training_iteration(trainer, warmup_iterations)
-        trainer.graceful_close()
+        trainer, err = None, None
+        try:
+            trainer = train_script.setup_trainer("tag_continuous", ov, results_dir=results_dir or tmp, verbose=False)
+        except Exception as e:  # noqa: BLE001 -- every rank must learn of it before the first collective of the iteration
+            err = e
+        if not wdd.all_ranks_ok(err is None):
+            if trainer is not None:
+                trainer.graceful_close()
+            raise RuntimeError(f"trainer set-up failed on {'this rank: ' + type(err).__name__ + ': ' + str(err) if err else 'another rank'}")
+        try:
+            out = measure_training_iteration(trainer, warmup_iterations)
+        finally:
+            trainer.graceful_close()
     return out

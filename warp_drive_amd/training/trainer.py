@@ -262,11 +262,19 @@ class Trainer:
                 need = sum(4 * self.batch_len * E * len(self.policy_map[pol]) * (2 * fw[0].H + W) for pol in self.policies)
                 free = torch.cuda.mem_get_info(self.device)[0]
                 if need <= free // 2:
-                    self._stored = {}
-                    for pol in self.policies:
-                        n = len(self.policy_map[pol])
-                        self._stored[pol] = tuple(torch.empty((self.batch_len, E, n, c), dtype=torch.float32, device=self.device)
-                                                  for c in (fw[0].H, fw[0].H, W)) if config["policy"][pol]["to_train"] else None
+                    try:
+                        self._stored = {}
+                        for pol in self.policies:
+                            n = len(self.policy_map[pol])
+                            self._stored[pol] = tuple(torch.empty((self.batch_len, E, n, c), dtype=torch.float32, device=self.device)
+                                                      for c in (fw[0].H, fw[0].H, W)) if config["policy"][pol]["to_train"] else None
+                    except torch.cuda.OutOfMemoryError:
+                        # somebody else took the memory between the check and the allocation (another rank on the same
+                        # device, another process): the buffers are an optimisation, not a requirement
+                        self._stored = None
+                        torch.cuda.empty_cache()
+                        logging.warning(f"reuse_rollout_activations: {need / 2**30:.1f} GiB of buffers could not be allocated; the "
+                                        "update recomputes its forward pass")
                 else:
                     logging.warning(f"reuse_rollout_activations: {need / 2**30:.1f} GiB of buffers do not fit half of the free "
                                     f"memory ({free / 2**30:.1f} GiB); the update recomputes its forward pass")
