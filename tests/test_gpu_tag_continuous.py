@@ -695,6 +695,23 @@ def test_candidates_a_few_ulps_apart_at_the_cut(K, n_runners):
             np.testing.assert_array_equal(got[e], want[e], err_msg=f"K={K} t={t} case (delta, swap, triple)={cases[e]}")
 
 
+@pytest.mark.parametrize("runners,E,ticks,kernel", [(1000, 40, 30, "HipTagContinuousTick_K10_N1024"),
+                                                    (500, 64, 40, "HipTagContinuousTick_K10_N512"),
+                                                    # most of an episode: the cell grid shrinks from 8 x 8 to 4 x 4 with the
+                                                    # agents in the game, then the packing goes back to id order
+                                                    (1000, 6, 430, "HipTagContinuousTick_K10_N1024")])
+def test_big_replicas_of_the_bench_configuration_vs_c_oracle(runners, E, ticks, kernel):
+    """The configurations `bench.py --num-runners 1000 / 500` times (BASELINE's physics, 5 taggers, 21-way heads, the uniform
+    policy; cell-sorted, prefiltered neighbour search with its hints alive from tick 1 on): E replicas that drift apart
+    through their own sampled actions, every tick of the fused kernel against the C oracle -- actions draw for draw, state,
+    rewards, done, observation rows and nearest_neighbor_ids, tolerance 0."""
+    cfg = dict(BENCH_CFG, num_runners=runners)
+    live_seen, id_rows, id_pads, rows = _fused_ticks_vs_c_oracle(cfg, E, ticks, 7, kernel=kernel)
+    assert live_seen[0] > 0.9 * (runners + 5) and id_rows > 0.8 * E * ticks * live_seen[-1]
+    if ticks > 400:
+        assert live_seen[-1] < 0.4 * (runners + 5), live_seen[-1]
+
+
 @pytest.mark.parametrize("side,spacing,kernel", [(32, 0.625, "HipTagContinuousStep_K10_N1024"),
                                                  (20, 1.0, "HipTagContinuousStep_K10_N512")])
 def test_cell_sorted_search_on_a_lattice_of_exact_ties(side, spacing, kernel):
