@@ -15,7 +15,9 @@ for update, rollout, fused, fast, arith in CASES:
                       "fused_policy_forward": fused, "fused_tick": fast, "policy_arithmetic": arith.split("-")[0],
                       "reuse_rollout_activations": "no-reuse" not in arith}}
     tr = setup_trainer("tag_continuous", ov, results_dir=f"/tmp/rt_{update}_{rollout}_{int(fused)}_{int(fast)}_{arith}", verbose=False)
-    tr._generate_rollout_batch(); torch.cuda.synchronize()
+    for _ in range(3):  # (the second rollout of a fresh trainer carries a one-off ~70 ms: 22 / 91 / 20 / 20 ms measured)
+        tr._generate_rollout_batch()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): tr._generate_rollout_batch()
     torch.cuda.synchronize()
