@@ -439,6 +439,47 @@ def test_cartpole_rollout_records_every_tick(E, n_launches):
     batches is tick k of the launch -- the observation the action was sampled on, the action (draw for draw),
     the reward and the done flag -- replayed through the oracle; the per-tick arrays hold the last tick.
     (trainer_base.py:392-426 records exactly these per tick.)"""
+    assert _cartpole_recorded_rollout(E, n_launches) == 1  # (the classic physics: the middle ticks run cp_euler<true>)
+
+
+def test_cartpole_fast_middle_ticks_rest_on_checked_claims():
+    """The middle ticks of a recorded Cartpole launch use a quadrant-free sin / cos and a three-instruction division by the
+    total mass (csrc/kernels/cartpole.hip: cp_euler<true>).  Both are claims about float32 arithmetic, checked exhaustively on
+    the device: cp_sincos_small == the numpy-exact sin / cos for every float32 of [-0.75, 0.75]; the division shortcut ==
+    the correctly rounded division for the env's total mass (2^25 dividends) -- and the checker does notice a wrong claim: handed
+    a reciprocal that is one ulp off it reports failure (then the env would report 0 and the kernels divide)."""
+    import torch
+    from tests.hip_harness import make_wrapper, require_gpu
+    from warp_drive_amd.envs.cartpole import CUDAClassicControlCartPoleEnv
+
+    require_gpu()
+    env = CUDAClassicControlCartPoleEnv(episode_length=20, seed=1)
+    w = make_wrapper(env, 8)
+    fm = w.cuda_function_manager
+    fm.initialize_functions(["HipCartPoleVerifySmallAngle", "HipCartPoleVerifyInvariantDivide"])
+    ok = torch.ones(1, dtype=torch.int32, device="cuda")
+    fm.get_function("HipCartPoleVerifySmallAngle")(ok, block=(256, 1, 1), grid=(4096, 1), shared=0)
+    assert int(ok.item()) == 1
+    assert env.invariant_divide_ok() == 1
+    verify = fm.get_function("HipCartPoleVerifyInvariantDivide")
+    for c in (np.float32(1.1), np.float32(2.0 - 2.0 ** -23), np.float32(3.0)):
+        y = np.float32(1.0) / c
+        for recip, want in ((y, 1), (np.nextafter(y, np.float32(2.0)), 0), (np.nextafter(y, np.float32(0.0)), 0)):
+            ok.fill_(1)
+            verify(c, recip, ok, block=(256, 1, 1), grid=(4096, 1), shared=0)
+            assert int(ok.item()) == want, (c, recip)
+
+
+@pytest.mark.parametrize("physics,fast", [(dict(masscart=1.3, division_proof_failed=True), 0),  # (forced) the kernels divide
+                                          (dict(theta_threshold_radians=0.9), 1),            # angles beyond 0.75: general sin / cos
+                                          (dict(masspole=0.25, length=0.8, force_mag=7.0), 1)])
+def test_cartpole_recorded_rollout_with_other_physics(physics, fast):
+    """the recorded rollout stays bit-exact where the fast middle ticks' preconditions do NOT hold (the kernel decides once
+    per launch and wavefront) and for other constants where they do"""
+    assert _cartpole_recorded_rollout(1500, 5, physics) == fast
+
+
+def _cartpole_recorded_rollout(E, n_launches, physics=None):
     import torch
     from oracle.cartpole_np import CartPoleOracle
     from oracle.core_np import sample_actions_counting, single_head_tick_uniform
@@ -451,6 +492,13 @@ def test_cartpole_rollout_records_every_tick(E, n_launches):
     require_gpu()
     T, ticks = 23, 16  # (E = 100 000: BASELINE configs[4]'s own size)
     env = CUDAClassicControlCartPoleEnv(episode_length=T, seed=32145)
+    oracle_cls = CartPoleOracle
+    if physics:  # the same constants for the env (class CartPolePhysics) and the oracle (class attributes)
+        physics = dict(physics)
+        if physics.pop("division_proof_failed", False):
+            env._inv_div_ok = 0  # what invariant_divide_ok() would cache had the exhaustive check failed
+        env.physics = type("Physics", (env.physics,), physics)
+        oracle_cls = type("Oracle", (CartPoleOracle,), physics)
     env.ticks_per_launch = ticks
     w = make_wrapper(env, E)
     sampler = HIPSampler(w.cuda_function_manager)
@@ -463,7 +511,7 @@ def test_cartpole_rollout_records_every_tick(E, n_launches):
              "done": torch.full((ticks, E), -1, dtype=torch.int32, device="cuda")}
     engine = RolloutEngine(w, sampler, probabilities=[probs], rollout_batch=batch)
     assert engine.fused and engine.ticks_per_launch == ticks
-    orc = CartPoleOracle(E, T, initial_state=pull(w, "state")[0, 0])
+    orc = oracle_cls(E, T, initial_state=pull(w, "state")[0, 0])
     rng_words = np.zeros(4 + E, dtype=np.uint32)
     probs_host = probs.cpu().numpy()
     finished = 0
@@ -487,6 +535,7 @@ def test_cartpole_rollout_records_every_tick(E, n_launches):
         np.testing.assert_array_equal(pull(w, "_timestep_"), orc.timestep)
         np.testing.assert_array_equal(pull(w, OBS)[:, 0], orc.obs)  # finished replicas already hold the reset observation
     assert finished >= n_launches // 2 * E
+    return env.invariant_divide_ok()
 
 
 @pytest.mark.parametrize("hidden", [32, 64])

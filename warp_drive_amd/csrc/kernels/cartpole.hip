@@ -19,17 +19,73 @@ namespace {
 struct CpPhysics {
   float gravity, masspole, total_mass, length, polemass_length, force_mag, tau;
   float theta_threshold_radians, x_threshold;
+  float inv_total_mass;  // RN(1 / total_mass) (correctly rounded: -fhip-fp32-correctly-rounded-divide-sqrt)
 };
 
+// x / c for a divisor that is the same on every tick of every replica (the total mass): q = RN(x * y), r = x - c * q
+// (exact: one FMA), RN(q + r * y), y = RN(1 / c) -- three instructions instead of the ~10 of the correctly rounded division.
+// Equal to RN(x / c) for ALL normal x away from underflow / overflow iff it is for the 2^24 values of one binade and both signs
+// (scaling x by a power of two scales q, r and the result exactly): HipCartPoleVerifyInvariantDivide checks exactly that for
+// the env's own c, exhaustively, once per env object (no float32 divisor tried so far fails it; the proof is per divisor all the
+// same: the classical guarantee has exceptions, and an exhaustive check costs one launch); the launch
+// uses this form only with that proof in hand, and only for dividends inside [2^-90, 2^90] (cp_euler<true>).
+__device__ __forceinline__ float cp_div_invariant(float x, float c, float y) {
+  const float q = x * y;
+  const float r = __builtin_fmaf(-c, q, x);
+  return __builtin_fmaf(r, y, q);
+}
+
+// numpy's float32 sin / cos kernel (wd_np_sincosf) for |x| <= 0.75: the quadrant is 0 -- RN(x * 2/pi + magic) - magic = 0
+// exactly (|x * 2/pi| < 0.478) and the three reduction FMAs return x itself -- so the reduction and the quadrant selects drop
+// out: the same two polynomials on r = x, bit for bit (checked against wd_np_sincosf for every float32 in [-0.75, 0.75] by
+// tests/test_gpu_core.py).  A pole beyond 12 degrees has fallen: the angle of a replica that is still running is below 0.21.
+__device__ __forceinline__ void cp_sincos_small(float x, float &sin_out, float &cos_out) {
+  const float r2 = x * x;
+  float c = __builtin_fmaf(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
+  c = __builtin_fmaf(c, r2, 0x1.55553cp-05f);
+  c = __builtin_fmaf(c, r2, -0x1.000000p-01f);
+  c = __builtin_fmaf(c, r2, 0x1.000000p+00f);
+  float sn = __builtin_fmaf(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+  sn = __builtin_fmaf(sn, r2, 0x1.11119ap-07f);
+  sn = __builtin_fmaf(sn, r2, -0x1.555556p-03f);
+  sn = __builtin_fmaf(sn, r2, 0.0f);
+  sn = __builtin_fmaf(sn, x, x);
+  sin_out = sn;
+  cos_out = c;
+}
+
 // one Euler update, cartpole_step_numba.py:42-78 (float32 state; everything downstream of the
-// Python literal 4.0/3.0 in float64, as Numba types it)
+// Python literal 4.0/3.0 in float64, as Numba types it).
+// FAST (compile time; the middle ticks of a recorded launch whose PRECONDITIONS the kernel checked once, cp_tick_impl):
+// |theta| <= 0.75 on entry -> the quadrant-free sin / cos; the two float32 divisions by the total mass in three
+// instructions each.  Bit-identical to the general form: the one data-dependent condition left -- a dividend outside the
+// range the division shortcut was proved for (the force term's dividend; the other one is the pole's mass times cos^2) --
+// redoes both divisions in a cold block behind a branch that is never taken in practice (the dividends are ~10 and ~0.1).
+template <bool FAST = false>
 __device__ __forceinline__ bool cp_euler(float4 &s, int action, const CpPhysics &p) {
   float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
   const float force = (action > 0) ? p.force_mag : -p.force_mag;  // action > 0.5
   float sintheta, costheta;
-  wd_np_sincosf(theta, sintheta, costheta);
-  const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) / p.total_mass;
-  const double den = (double)p.length * (4.0 / 3.0 - (double)(p.masspole * (costheta * costheta) / p.total_mass));
+  if (FAST) cp_sincos_small(theta, sintheta, costheta);
+  else wd_np_sincosf(theta, sintheta, costheta);
+  const float temp_num = force + p.polemass_length * (theta_dot * theta_dot) * sintheta;
+  const float frac_num = p.masspole * (costheta * costheta);
+  float temp, frac;
+  if (FAST) {
+    temp = cp_div_invariant(temp_num, p.total_mass, p.inv_total_mass);
+    frac = cp_div_invariant(frac_num, p.total_mass, p.inv_total_mass);
+    // |temp_num| inside [2^-90, 2^90) by its exponent field (zero, subnormal, infinite, NaN: outside); frac_num is the pole's
+    // mass (inside [2^-60, 2^60]: a precondition of the launch) times cos^2 >= 0.53: always inside
+    const bool in_range = ((__float_as_uint(temp_num) & 0x7fffffffu) - 0x12800000u) < 0x5a000000u;
+    if (__builtin_expect(__ballot(!in_range) != 0ull, 0)) {
+      temp = temp_num / p.total_mass;
+      frac = frac_num / p.total_mass;
+    }
+  } else {
+    temp = temp_num / p.total_mass;
+    frac = frac_num / p.total_mass;
+  }
+  const double den = (double)p.length * (4.0 / 3.0 - (double)frac);
   const double thetaacc = (double)(p.gravity * sintheta - costheta * temp) / den;
   const double xacc = (double)temp - (double)p.polemass_length * thetaacc * (double)costheta / (double)p.total_mass;
   x = x + p.tau * x_dot;
@@ -144,8 +200,9 @@ __device__ __forceinline__ void cp_store_s(const void *sbase, uint32_t voff, flo
 
 // BATCH: the four `*_batch` pointers are given (every tick recorded) -- a compile-time copy of the loop for each case, so
 // that the tick carries no "is there a batch" branches
-struct CpTrue { static constexpr bool value = true; };
-struct CpFalse { static constexpr bool value = false; };
+struct CpTrue { static constexpr bool value = true, fast = false; };
+struct CpFalse { static constexpr bool value = false, fast = false; };
+struct CpTrueFast { static constexpr bool value = true, fast = true; };  // a middle tick with cp_euler<true>
 
 // A2: exactly two actions (Cartpole's own action space), known at compile time
 template <int H, bool BATCH, bool A2 = false>
@@ -157,9 +214,9 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
     int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
     int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
-    const float *policy, int hidden) {
+    const float *policy, int hidden, int invariant_divide_ok) {
   const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
-                    theta_threshold_radians, x_threshold};
+                    theta_threshold_radians, x_threshold, 1.0f / total_mass};
   const CpResetEntry *table = (const CpResetEntry *)reset_table;
   const uint32_t k0 = rng_state[0], k1 = rng_state[1];
   if (H > 0) {
@@ -252,7 +309,7 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
       // ---- step
       if (BATCH) cp_store_s(ob_k, off16, s);  // the observation this action was sampled on
       t += 1;
-      const bool terminated = cp_euler(s, a, p);
+      const bool terminated = cp_euler<decltype(mid_tag)::fast>(s, a, p);
       const bool fin = (t == episode_length) || terminated;
       if (BATCH) {
         cp_store_s(ab_k, off4, a);
@@ -302,7 +359,14 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
       }
     };
     if (lazy) {  // (uniform) every tick but the last: the branch-free body
-      for (int k = 0; k < ticks - 1; ++k) tick(k, CpTrue{}, false);
+      // cp_euler<true>'s preconditions, checked ONCE per launch and wavefront: the division shortcut is proved for this total
+      // mass (host flag), a running replica's angle stays inside 0.75 (threshold), and so do the angles the wavefront starts
+      // from and restarts from.  A middle tick then only ever sees the restart state or a state that did not terminate.
+      const bool small = (p.theta_threshold_radians <= 0.75f) && (fabsf(s.z) <= 0.75f) && (fabsf(s_restart.z) <= 0.75f);
+      const bool mass_ok = (p.masspole >= 0x1.0p-60f) && (p.masspole <= 0x1.0p60f);
+      const bool fast = (invariant_divide_ok != 0) && mass_ok && (__ballot(!small) == 0ull);  // (wave-uniform)
+      if (fast) for (int k = 0; k < ticks - 1; ++k) tick(k, CpTrueFast{}, false);
+      else for (int k = 0; k < ticks - 1; ++k) tick(k, CpTrue{}, false);
       tick(ticks - 1, CpFalse{}, true);
     } else {
       for (int k = 0; k < ticks; ++k) tick(k, CpFalse{}, k == ticks - 1);
@@ -316,6 +380,35 @@ __device__ __forceinline__ void cp_tick_impl(float *cp_weights,
 
 extern "C" {
 
+// Exhaustive proof for ONE divisor c (the env's total mass) that cp_div_invariant(x, c, RN(1 / c)) == x / c for every
+// float32 x of one binade, both signs (2^24 values; all other normal x follow by scaling): `ok` (preset to 1 by the host)
+// is cleared on the first mismatch (a test hands it a reciprocal that is one ulp off: it must notice).  Run once per env
+// object (envs/cartpole.py::invariant_divide_ok).
+__global__ void HipCartPoleVerifyInvariantDivide(float c, float y, int *ok) {  // y: RN(1 / c), formed by the host
+  if (y != 1.0f / c && threadIdx.x == 0 && blockIdx.x == 0) *ok = 0;  // (not what the tick kernels use: 1.0f / total_mass)
+  // bits 0 .. 22: the significand; bit 23: a second binade (x 2^40: the scaling argument, spot-checked); bit 24: the sign
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << 25); i += gridDim.x * blockDim.x) {
+    const float m = __uint_as_float(0x3f800000u | (i & 0x7fffffu) | ((i >> 24) << 31));
+    const float x = ((i >> 23) & 1u) ? m * 0x1.0p40f : m;
+    const float want = x / c, got = cp_div_invariant(x, c, y);
+    if (__float_as_uint(want) != __float_as_uint(got)) *ok = 0;
+  }
+}
+
+// cp_sincos_small against wd_np_sincosf for every float32 of [-0.75, 0.75] (the test of the claim in its comment)
+__global__ void HipCartPoleVerifySmallAngle(int *ok) {
+  const uint32_t top = __float_as_uint(0.75f);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= top; i += gridDim.x * blockDim.x) {
+    const float xs[2] = {__uint_as_float(i), __uint_as_float(i | 0x80000000u)};
+    for (int k = 0; k < 2; ++k) {
+      float s0, c0, s1, c1;
+      wd_np_sincosf(xs[k], s0, c0);
+      cp_sincos_small(xs[k], s1, c1);
+      if (__float_as_uint(s0) != __float_as_uint(s1) || __float_as_uint(c0) != __float_as_uint(c1)) *ok = 0;
+    }
+  }
+}
+
 __global__ void HipClassicControlCartPoleEnvStep(
     float4 *__restrict__ state_arr, const int *__restrict__ action_arr, int *__restrict__ done_arr,
     float *__restrict__ reward_arr, float4 *__restrict__ observation_arr, float gravity,
@@ -323,7 +416,7 @@ __global__ void HipClassicControlCartPoleEnvStep(
     float tau, float theta_threshold_radians, float x_threshold,
     int *__restrict__ env_timestep_arr, int episode_length, int n_envs) {
   const CpPhysics p{gravity, masspole, total_mass, length, polemass_length, force_mag, tau,
-                    theta_threshold_radians, x_threshold};
+                    theta_threshold_radians, x_threshold, 1.0f / total_mass};
   for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < n_envs; env += gridDim.x * blockDim.x) {
     const int t = env_timestep_arr[env] + 1;
     env_timestep_arr[env] = t;
@@ -344,13 +437,13 @@ __global__ void HipClassicControlCartPoleEnvTick(
     int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state,
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays,
     int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch,
-    const float *policy, int hidden) {
+    const float *policy, int hidden, int invariant_divide_ok) {
   if (obs_batch && n_actions == 2)  // the recorded two-action rollout (configs[4]): sizes folded
-    cp_tick_impl<0, true, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+    cp_tick_impl<0, true, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden, invariant_divide_ok);
   else if (obs_batch)
-    cp_tick_impl<0, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+    cp_tick_impl<0, true>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden, invariant_divide_ok);
   else
-    cp_tick_impl<0, false>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden);
+    cp_tick_impl<0, false>(nullptr, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden, invariant_divide_ok);
 }
 
 // the rollout with a live policy (weights in dynamic LDS); `hidden` must equal the entry's width
@@ -363,12 +456,12 @@ __global__ void HipClassicControlCartPoleEnvTick(
     int *env_timestep_arr, int episode_length, int n_envs, uint32_t *rng_state, \
     const float *__restrict__ probs, int n_actions, const void *reset_table, int n_reset_arrays, \
     int stream_tag, int ticks, float4 *obs_batch, int *action_batch, float *reward_batch, int *done_batch, \
-    const float *policy, int hidden) {           \
+    const float *policy, int hidden, int invariant_divide_ok) {           \
     extern __shared__ __attribute__((aligned(16))) float cp_lds[];                                 \
     if (obs_batch)                                                                                 \
-      cp_tick_impl<HH, true>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden); \
+      cp_tick_impl<HH, true>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden, invariant_divide_ok); \
     else                                                                                           \
-      cp_tick_impl<HH, false>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden); \
+      cp_tick_impl<HH, false>(cp_lds, state_arr, action_arr, done_arr, reward_arr, observation_arr, gravity, masspole, total_mass, length, polemass_length, force_mag, tau, theta_threshold_radians, x_threshold, env_timestep_arr, episode_length, n_envs, rng_state, probs, n_actions, reset_table, n_reset_arrays, stream_tag, ticks, obs_batch, action_batch, reward_batch, done_batch, policy, hidden, invariant_divide_ok); \
   }
 WD_CP_ROLLOUT(32)
 WD_CP_ROLLOUT(64)

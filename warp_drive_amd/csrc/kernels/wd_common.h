@@ -99,8 +99,12 @@ __device__ __forceinline__ uint32_t wd_tick_draw(uint32_t row, uint32_t epoch, u
     blk = wd_philox4x32_10(wd_u4{row, quad, stream_tag, 4u}, k0, k1);
     blk_quad = quad;
   }
-  const uint32_t w = epoch & 3u;
-  return (w == 0u) ? blk.x : (w == 1u) ? blk.y : (w == 2u) ? blk.z : blk.w;
+  // word (epoch & 3) of the block by bit masks: two sign-extended bit fields and three bit-field inserts -- the chain of
+  // ternaries on a per-lane index was compiled into three exec-mask branches per draw (a tick of the Cartpole rollout is
+  // ~150 instructions: the branches showed)
+  const uint32_t m0 = 0u - (epoch & 1u), m1 = 0u - ((epoch >> 1) & 1u);
+  const uint32_t lo = (blk.y & m0) | (blk.x & ~m0), hi = (blk.w & m0) | (blk.z & ~m0);
+  return (hi & m1) | (lo & ~m1);
 }
 
 // uniform in (0, 1], 24 random bits  (curand_uniform's range, random.cu:72)

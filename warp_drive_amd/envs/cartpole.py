@@ -195,8 +195,26 @@ class CUDAClassicControlCartPoleEnv(CUDAEnvironmentContext, ClassicControlCartPo
         else:
             batch_args = [null, null, null, null]
         args = list(args) + [sampler.rng_state, probabilities[0], np.int32(probabilities[0].shape[-1]), reset_args[0],
-                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)] + batch_args + pol_args
+                             reset_args[1], _stream_tag("tick"), np.int32(self.ticks_per_launch)] + batch_args + pol_args + \
+            [np.int32(self.invariant_divide_ok())]
         return fm.get_function(name), args, block, grid, shared
+
+    def invariant_divide_ok(self):
+        """1 when the device PROVED, exhaustively, that the tick kernels' three-instruction division by this env's total mass
+        (csrc/kernels/cartpole.hip::cp_div_invariant) equals the correctly rounded division for every float32 dividend of two
+        binades, both signs -- one launch of HipCartPoleVerifyInvariantDivide, once per env object; 0: the kernels divide.
+        (True for the classic 1.1 and for every other mass tried so far.)"""
+        if getattr(self, "_inv_div_ok", None) is None:
+            import torch
+
+            fm = self.cuda_function_manager
+            fm.initialize_functions(["HipCartPoleVerifyInvariantDivide"])
+            ok = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            total_mass = np.float32(self.physics.masspole + self.physics.masscart)
+            fm.get_function("HipCartPoleVerifyInvariantDivide")(total_mass, np.float32(1.0) / total_mass, ok,
+                                                                block=(256, 1, 1), grid=(4096, 1), shared=0)
+            self._inv_div_ok = int(ok.item())
+        return self._inv_div_ok
 
     def step(self, actions=None):
         self.timestep += 1
