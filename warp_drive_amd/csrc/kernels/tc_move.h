@@ -9,6 +9,20 @@ namespace {
 
 // ---- move: float32 kinematics exactly as numpy evaluates update_state (:339-401); stores the new
 // state, returns the post-move position, the edge penalty and the observation features.
+// numpy's float32 remainder by 2 pi (npy_divmodf: fmodf, then the divisor's sign) for the only dividends a heading ever
+// produces -- an angle of [0, 2 pi) plus one turn: |a| < 4 pi.  fmodf is EXACT by definition, and for |a| < 2 b it is a or
+// a -+ b, the subtraction exact (Sterbenz: b <= |a| < 2 b): five branch-free instructions instead of the library's long
+// division (~40 executed instructions and four exec-mask branches per agent and tick).  Anything else -- a heading somebody
+// wrote into the state array, an action table with turns beyond 2 pi, NaN -- takes the library path in a cold block.
+__device__ __forceinline__ float tc_remainder_two_pi(float a, float b) {
+  const float aa = fabsf(a);
+  if (__builtin_expect(__ballot(!(aa < 2.0f * b)) != 0ull, 0)) return wd_np_remainderf(a, b);  // (wave-uniform, never in practice)
+  float m = aa - ((aa >= b) ? b : 0.0f);   // |fmodf(a, b)|, exact
+  m = (a < 0.0f && m != 0.0f) ? b - m : m; // fmodf carries the dividend's sign; a negative remainder gets + b (one rounding,
+                                           // the same one: -m + b); zero stays +0 (copysignf(0, b), b > 0)
+  return m;
+}
+
 struct TcMoved {
   float x, y, edge_pen;
   TcFeat ft;
@@ -27,7 +41,7 @@ __device__ __forceinline__ TcMoved tc_move(const TcArgs &a, const TcTables &tb, 
     d_acc = a.acc_actions[act.x];
     d_turn = a.turn_actions[act.y];
   }
-  const float dir = wd_np_remainderf(in.dir + d_turn, two_pi) * s;            // :355-357
+  const float dir = tc_remainder_two_pi(in.dir + d_turn, two_pi) * s;          // :355-357
   float acc = in.acc + d_acc;                                                 // :359
   const float vmax = a.max_speed * in.skill;                                  // :363
   float v = in.speed + acc;

@@ -170,13 +170,15 @@ __device__ __forceinline__ int wd_slab_sample(const float *row, int n, float u) 
 #pragma unroll
     for (int i = 0; i < WD_SLAB_CH; ++i) p[i] = row[i];  // immediate offsets; entries >= n are the next row's
                                                     // (or, after the last row, table bytes): read, masked off below
-    // one compare + one shift-in-the-carry add per entry (m = 2m + [cum < u]); the entries past n are
-    // dropped with one AND at the end instead of a range check per entry
+    // one subtraction + one funnel shift per entry: the sign of cum - u IS [cum < u] (equal gives +0), shifted into the
+    // mask by v_alignbit (m = 2m + sign) -- two full-rate instructions where v_cmp + v_addc (carry in and out) take ~3
+    // cycles each on gfx950 (experiments/README.md); the entries past n are dropped with one AND at the end instead of a
+    // range check per entry
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < WD_SLAB_CH; ++i) {
       cum = (i == 0) ? p[0] : cum + p[i];
-      asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(cum), "v"(u) : "vcc");
+      m = __builtin_amdgcn_alignbit(m, __float_as_uint(cum - u), 31);
     }
     // entry i sits on bit WD_SLAB_CH-1-i
     cnt = __popc(m & (((1u << n) - 1u) << (WD_SLAB_CH - n)));
