@@ -229,7 +229,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // i: wavefront 0 runs the chain over the first half of the candidates, wavefront 1 over the second half; wavefront
   // 1 hands its L keys over through its staging buffer (dead until the gather) and wavefront 0 merges the two sorted
   // lists (tc_merge_sorted: the L smallest of the union are exactly what one chain over all candidates keeps).
-  constexpr int L = KMAX + 3;  // self + K others + two look-ahead entries
+  // self + K others + the look-ahead entries: two; ONE where K == KMAX is known and the replica has at most 128 agents (the
+  // BASELINE shape's entries): one v_med3_u32 less per candidate, near-ties at the cut go to tc_zone_resolve (tc_resolve_keys)
+  constexpr int L = KMAX + ((EXACTK && IDB == 7) ? 2 : 3);
   const bool split = compact && (n_waves == 2) && (n_live <= 64) && (n_live >= 16) &&
                      (l.stage_dwords >= 64 * L);                          // block-uniform
   const int j_half = split ? (((n_live + 7) >> 3) << 2) : n_cand;        // first candidate of wavefront 1's half
@@ -398,7 +400,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         h[1] = make_uint4(w[4], w[5], w[6], w[7]);
       }
     }
-    if (!exact && (IDB == 7 || n_cand <= 128)) {
+    if (!exact && !(EXACTK && IDB == 7) && (IDB == 7 || n_cand <= 128)) {
       WD_TC_PROBE_VAL(20, 1);
       int nid2[KMAX], rank2[KMAX];
 #pragma unroll
@@ -412,9 +414,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
       exact = true;
     }
   }
-  if constexpr (IDB != 7) {
-    // more than 128 candidates: the lanes that need the exact resolution get it from the whole wavefront, one
-    // after the other (tc_zone_resolve)
+  if constexpr (IDB != 7 || EXACTK) {
+    // more than 128 candidates, or the chain with ONE look-ahead entry (L above): the lanes that need the exact resolution
+    // get it from the whole wavefront, one after the other (tc_zone_resolve)
     unsigned long long need = __ballot(searcher && !exact);  // wave-uniform
     if (need != 0ull) {
       WD_TC_PROBE_VAL(20, 1);
@@ -427,7 +429,9 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
         const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my), fl));
         const unsigned zh = (unsigned)__builtin_amdgcn_readlane((int)zone_hi, fl);
         const int self = __builtin_amdgcn_readlane(ag, fl);
-        const int cnt = tc_zone_resolve<TIE_TABLE>(sxy, n_cand, sx, sy, self, zh, IDB, K, (unsigned char *)stage, lane, l.cid);
+        // (several replicas per block -- small replicas, never packed: the candidates are the replica's of lane fl)
+        const float2 *const zxy = compact ? sxy : l.xy + __builtin_amdgcn_readlane(el, fl) * NP;
+        const int cnt = tc_zone_resolve<TIE_TABLE>(zxy, n_cand, sx, sy, self, zh, IDB, K, (unsigned char *)stage, lane, l.cid);
         if (cnt > 64) {
           unresolved |= 1ull << fl;
         } else {

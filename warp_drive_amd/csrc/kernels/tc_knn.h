@@ -708,11 +708,18 @@ __device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, fl
 // at least 2^(IDB-1) - 1 ulps of the float32 distance)
 // S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
 // agent's own entry (the caller remembers their ids for the next tick's bound)
+// L = KMAX + 3: two look-ahead entries behind the K-th other agent (any K <= KMAX).  L = KMAX + 2 (round 6; K == KMAX only:
+// the shape-specialised and the exact-K entries of replicas up to 128 agents): ONE look-ahead entry, one v_med3_u32 less per
+// candidate and searcher.  The (K+1)-th other agent is then the last thing the chain knows: whenever IT lies inside the
+// uncertain buckets (~3e-4 per agent), or forms a close pair with the K-th (~5e-4), what lies behind it is unknown and the
+// function returns false -- the caller has the whole wavefront resolve the zone for that lane (tc_zone_resolve: ~150
+// instructions, where the two-pass repeat of round 2 cost a whole search and the launch waited for it).
 template <int KMAX, int IDB, int L, bool TABLE = false>
 __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K, const unsigned (&S)[L],
                                                 unsigned (&o)[L - 1], int (&nid)[KMAX + 1], int (&rank)[KMAX + 1],
                                                 bool &in_order, const short *tie = nullptr) {
-  static_assert(L >= KMAX + 3, "self + K others + two look-ahead entries");
+  static_assert(L == KMAX + 3 || L == KMAX + 2, "self + K others + two look-ahead entries (one: K == KMAX only)");
+  constexpr bool ONE_LOOK = (L == KMAX + 2);
   constexpr unsigned IDM = (1u << IDB) - 1u;
   const float xi = cxy[ag].x, yi = cxy[ag].y;
   // drop the agent's own entry (d2 = 0 exactly: key == ag).  It is the first entry unless a twin with
@@ -770,10 +777,11 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
     constexpr unsigned THR = 3u * (IDM + 1u) - 1u;
     unsigned cm = 0u;  // bit k: keys k and k + 1 are close (k = K: the pair behind the cut)
 #pragma unroll
-    for (int k = 0; k <= KMAX; ++k)
+    for (int k = 0; k <= (ONE_LOOK ? KMAX - 1 : KMAX); ++k)
       if (k <= K) cm |= ((o[k + 1] - o[k] < THR) ? 1u : 0u) << k;
     unsigned rel = cm & ((1u << K) - 1u);
-    const bool look_close = ((cm >> K) & 1u) != 0u;
+    // (one look-ahead entry: what follows the (K+1)-th is unknown -- as if it were close)
+    const bool look_close = ONE_LOOK ? true : ((cm >> K) & 1u) != 0u;
     simple = ((rel & (rel >> 1)) == 0u) && !(((rel >> (K - 1)) & 1u) != 0u && look_close);
     if (simple) {
       WD_TC_PROBE_VAL(23, 1);
@@ -802,15 +810,16 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
   if (!apart && !simple) {
     WD_TC_PROBE_VAL(22, 1);
     // the K-th, (K+1)-th and (K+2)-th other agent in chain order
-    unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[KMAX + 1];
+    unsigned oK = o[KMAX - 1], oExtra = o[KMAX], oLook = o[ONE_LOOK ? KMAX : KMAX + 1];
 #pragma unroll
     for (int k = 0; k < KMAX - 1; ++k) {
       oK = (k == K - 1) ? o[k] : oK;
       oExtra = (k == K - 1) ? o[k + 1] : oExtra;
-      oLook = (k == K - 1) ? o[k + 2] : oLook;
+      if constexpr (!ONE_LOOK) oLook = (k == K - 1) ? o[k + 2] : oLook;
     }
     const unsigned INVALID = 0x7f800000u;  // agents out of the game sit at +inf; unused slots are above
     const unsigned cut = (oK >> IDB) + 2u;   // first bucket that is certainly outside
+    // (one look-ahead entry: oLook IS the (K+1)-th -- certain only if that one is already outside)
     exact = (oK >= INVALID) || ((oLook >> IDB) >= cut);
     // positions of the first K entries (all reads in flight together), exact keys, ranks
     float2 pp[KMAX];
@@ -840,7 +849,8 @@ __device__ __forceinline__ bool tc_resolve_keys(const float2 *cxy, int ag, int K
     nid[KMAX] = -1;
     rank[KMAX] = KMAX;
     // the (K+1)-th entry is inside the uncertain buckets (~3e-4 per agent): it competes with the first K
-    if (oK < INVALID && oExtra < INVALID && (oExtra >> IDB) < cut) {
+    // (one look-ahead entry: that case returned `exact == false` above and is the caller's)
+    if (!ONE_LOOK && oK < INVALID && oExtra < INVALID && (oExtra >> IDB) < cut) {
       const int idE = (int)(oExtra & IDM);
       const float2 pe = cxy[idE];
       const float dx = xi - pe.x, dy = yi - pe.y;
