@@ -430,14 +430,14 @@ __device__ __forceinline__ void tc_merge_sorted(unsigned (&S)[L], const unsigned
 // ---- PREFILTERED search for replicas of more than 128 agents (round 4; one replica per block, K <= 12, used while at
 // least WD_TC_PRE_MIN_LIVE agents are in the game).  The chain costs 13 median-of-three (~3 cycles each with the VALU
 // saturated) + 6 cheap instructions per candidate and searcher and is VALU-bound on all sixteen wavefronts of a
-// 1005-agent replica: 80 % of its tick.  Agents move little per tick, so the searcher's K + 3 nearest others of the
-// PREVIOUS tick (32 bytes per agent in HBM, `knn_prev`) give a radius that holds the K nearest now (tc_knn_bound16):
-//   pass 1  every candidate: squared distance and ONE compare against the radius, shifted into a per-lane bit mask
-//           (v_cmp + v_addc: mask = 2 mask + bit) -- 7 instructions, 5 of them float32 add / mul at ~1.2 cycles;
-//   pass 2  the candidates whose bit is set (~15 per lane) go through the chain: every lane pops its own lowest set bit
-//           from its own list of non-empty mask words (round 6: tc_pre_pass2; lanes that ran out insert the pad
-//           position at +inf), as many trips as the fullest lane of the wavefront needs, with the next trip's
-//           position in flight.
+// 1005-agent replica: 80 % of its tick.  The searcher's K + 3 nearest others of the PREVIOUS tick (32 bytes per agent in
+// HBM, `knn_prev`) give a radius that holds the K nearest now (tc_knn_bound16); since round 6 the agents in the game are
+// packed by grid cell and the radius is also capped by the searcher's 3 x 3 cell block ("CELL-SORTED packing" below):
+//   pass 1  the candidates of the cell rows around the wavefront's searchers: squared distance and ONE subtraction from
+//           the radius whose sign is shifted into a per-lane bit mask (v_alignbit) -- 7 full-rate instructions;
+//   pass 2  the candidates whose bit is set (~21 per lane) go through the chain: every lane pops its own lowest set bit
+//           from its own list of non-empty mask words (tc_pre_pass1 / tc_pre_pass2), a lane leaves the loop when its list
+//           is empty: as many trips as the fullest lane of the wavefront has candidates.
 // At ~100 candidates this was measured and NOT adopted (a wash: pass 2 does not shrink with the number of
 // candidates); the break-even is at a few hundred.  What comes out is the K set the full chain
 // gives: the result is accepted only if the K-th other agent found lies at least TWO key buckets inside the radius
