@@ -530,7 +530,7 @@ def test_arena_empties_below_K_agents_at_the_headline_shape():
                                                                      (300, 6, 0.12, "HipTagContinuousTick_K10_N512")])
 def test_prefiltered_search_of_big_replicas(runners, taggers, tagging_distance, kernel):
     """Replicas of more than 128 agents search their neighbours inside a radius derived from the previous tick's
-    neighbours (`knn_prev`, tc_chain_prefiltered) while at least 200 agents are in the game.  70 ticks of a 45-tick
+    neighbours (`knn_prev`, tc_pre_pass1 / tc_pre_pass2) while at least 200 agents are in the game.  70 ticks of a 45-tick
     episode with a tagging distance that takes the arena from full to under 200 agents (prefilter on, then off) and
     back to full at the restart, every tick against the C oracle incl. nearest_neighbor_ids.  The hint is ONLY a
     hint: it is overwritten with random bits, with zeros (everybody remembers agents 0, 0, 0 ...), with one far

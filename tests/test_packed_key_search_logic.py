@@ -311,7 +311,7 @@ def test_two_wavefronts_key_lists_merge_to_the_single_chain_result(L):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Round 4: the PREFILTERED search of replicas of more than 128 agents (tc_knn_bound16 / tc_chain_prefiltered).
+# Round 4: the PREFILTERED search of replicas of more than 128 agents (tc_knn_bound16 / tc_pre_pass1 / tc_pre_pass2).
 # Only candidates inside a radius derived from the previous tick's neighbours reach the chain; the radius is a
 # heuristic, what makes the result exact is the check that the K-th other agent found lies at least two key buckets
 # inside it (then everything that was left out is past the buckets the decision rule above looks at).

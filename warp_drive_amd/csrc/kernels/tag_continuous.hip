@@ -41,7 +41,7 @@
 //                wavefront resolve the zone around the cut (tc_zone_resolve).  While at most 64 agents are in
 //                the game both wavefronts of a block chain half of the candidates each (tc_merge_sorted).  Replicas
 //                of more than 128 agents search inside a radius derived from the previous tick's neighbours while at
-//                least 200 agents are in the game (tc_chain_prefiltered: one compare per candidate, the chain over
+//                least 200 agents are in the game (tc_pre_pass1 / tc_pre_pass2, cell-sorted since round 6: one subtraction per candidate of the cell rows around a wavefront, the chain over
 //                the candidates inside the radius only, the radius checked afterwards);
 //       ids out  packed indices -> agent ids through an LDS table; 16-bit block-local ids per agent
 //                row in LDS (entry k -> slot k; out-of-order lanes rewrite their rows by rank); one

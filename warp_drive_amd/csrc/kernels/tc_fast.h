@@ -96,7 +96,7 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
     }
     my_c = before + __popcll(live_mask & ((1ull << lane) - 1ull));
   }
-  // the prefiltered search (tc_chain_prefiltered): on for big replicas while enough agents are in the game
+  // the prefiltered search (tc_pre_pass1 / tc_pre_pass2): on for big replicas while enough agents are in the game
   constexpr bool PRE = (IDB != 7) && (KMAX <= 12);
   // equal distances are settled by agent id through the packed-index -> id table wherever the candidates of a block may be
   // packed in another order than ascending id (tc_tie_order, tc_knn.h): replicas of more than 128 agents, one per block

@@ -706,7 +706,7 @@ __device__ __forceinline__ int tc_zone_resolve(const float2 *cxy, int n_cand, fl
 // IDB = id bits in the key: 7 for up to 128 candidates, 9 for up to 512, 10 for up to 1024 (buckets of 2^IDB ulps of d2;
 // the argument above holds for any bucket width: two buckets apart is more than 2^IDB ulps of d2, i.e.
 // at least 2^(IDB-1) - 1 ulps of the float32 distance)
-// S: the L smallest keys in ascending order (tc_chain_all / tc_chain_prefiltered); o: the same without the
+// S: the L smallest keys in ascending order (tc_chain_range / tc_pre_pass2); o: the same without the
 // agent's own entry (the caller remembers their ids for the next tick's bound)
 // L = KMAX + 3: two look-ahead entries behind the K-th other agent (any K <= KMAX).  L = KMAX + 2 (round 6; K == KMAX only:
 // the shape-specialised and the exact-K entries of replicas up to 128 agents): ONE look-ahead entry, one v_med3_u32 less per

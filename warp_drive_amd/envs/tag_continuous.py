@@ -279,7 +279,7 @@ class TagContinuous(CUDAEnvironmentContext):
         feed.add_data(name="obs_rows_cleared", data=np.zeros((n,), dtype=np.int32), save_copy_and_apply_at_reset=True)
         # Replicas of more than 128 agents: the ids (16 bits each, 0xffff = none) of every agent's K + 3 nearest
         # others of the previous tick, 32 bytes per agent -- the hint the prefiltered neighbour search starts from
-        # (tc_chain_prefiltered in the kernel file).  Only a hint: the kernel checks the radius it derives from it, so
+        # (tc_pre_pass1 / tc_pre_pass2 in csrc/kernels/tc_knn.h).  Only a hint: the kernel checks the radius it derives from it, so
         # the content never changes a result.  (Registered like per-replica state, which is what makes the wrapper
         # allocate one copy per replica; a reset then restores "none", and the first tick of the new episode searches
         # without a radius.)
