@@ -32,7 +32,9 @@
 //                are in the game on average over an episode of the benchmark policy).  Per searcher,
 //                in registers, ONE pass over the candidates: the candidate's packed index rides in
 //                the low 7 bits of the squared distance through a v_med3_u32 chain that keeps the
-//                K+3 smallest keys; where the first K+1 keys are far enough apart the chain order
+//                K+3 smallest keys (K+2 -- ONE look-ahead entry -- where K == KMAX is known and the replica
+//                has at most 128 agents: the BASELINE shape's entries; a near-tie at the cut, ~5e-4 per agent,
+//                then goes to tc_zone_resolve); where the first K+1 keys are far enough apart the chain order
 //                is the reference's order and the ids are read off the keys, otherwise the exact
 //                (sqrt(d^2), id) keys of the first K(+1) entries are ranked by pairwise
 //                compare-and-count -- an ISOLATED close pair by one exact compare of the two (round 4);
