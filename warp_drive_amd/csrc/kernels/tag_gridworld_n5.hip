@@ -162,7 +162,19 @@ __device__ __forceinline__ void gw5_rollout(
     }
   }
 
-  for (int env0 = blockIdx.x * GW5_EPB; env0 < n_envs; env0 += gridDim.x * GW5_EPB) {
+  // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), and a block's action / reward / done rows
+  // are 240 / 240 / 48 bytes: with replicas in blockIdx order every such row shares its first and last cache line with
+  // a block on ANOTHER XCD, whose L2 cannot merge the two halves.  Give each XCD a contiguous range of replica groups
+  // instead (a bijection of [0, gridDim.x) for any grid size); what a replica computes does not depend on its block.
+  // Measured (profiles/r06_ab_gridworld_block_order.txt): 20 000 replicas x 50 ticks 145.0 -> 127.8 us, 100 000 x 50
+  // 728 -> 688 us, 1 000 x 100 (84 blocks) equal within the run-to-run spread.
+#ifndef WD_GW5_BLOCK_ORDER_PLAIN
+  const int xcd = blockIdx.x & 7, nq = gridDim.x >> 3, nr = gridDim.x & 7;
+  const int group0 = xcd * nq + min(xcd, nr) + (blockIdx.x >> 3);
+#else
+  const int group0 = blockIdx.x;
+#endif
+  for (int env0 = group0 * GW5_EPB; env0 < n_envs; env0 += gridDim.x * GW5_EPB) {
     const int env = env0 + el;
     const bool active = (el < GW5_EPB) && (env < n_envs);
     const int idx = env * GW5_N + ag;
