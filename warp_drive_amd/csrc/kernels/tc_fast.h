@@ -49,7 +49,21 @@ __device__ __forceinline__ void tc_fast_impl(const TcArgs &a, const TcFuse &fz, 
   // used once and dies, which is what keeps the kernel inside 128 VGPRs / 104 SGPRs.
   // All global loads go out before anything else: the table set-up below (a dependent global load +
   // barrier) then runs in their shadow.
-  const int env0 = a.env_begin + blockIdx.x * epb;
+  // Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8).  A replica's rows of the state arrays are
+  // 4 * N bytes, so with replicas in blockIdx order the first and last cache line of every such row is shared with a
+  // block on ANOTHER XCD, whose L2 cannot merge the two halves before they go to memory.  Replicas of <= 128 agents
+  // get a contiguous range of replica groups per XCD instead (a bijection of [0, gridDim.x) for any grid size; what a
+  // replica computes does not depend on its block): headline tick 25.30 -> 24.81 us, 16 000 replicas 216 -> 210 us.
+  // Replicas of > 128 agents keep blockIdx order: their rows are long, and the same remap measured 2.5 % SLOWER at
+  // 500 replicas of 505 / 1005 agents (profiles/r06_ab_tc_block_order.txt).
+  int group = blockIdx.x;
+#ifndef WD_TC_BLOCK_ORDER_PLAIN
+  if constexpr (IDB == 7) {
+    const int bx = blockIdx.x & 7, bq = gridDim.x >> 3, br = gridDim.x & 7;
+    group = bx * bq + min(bx, br) + (int)(blockIdx.x >> 3);
+  }
+#endif
+  const int env0 = a.env_begin + group * epb;
   // Wave priority falls with the phase (3: fetch .. tags, 2: first half of the search, 0: the rest
   // of it and everything after, with a short stretch at 1 where the ids come out of the keys): a
   // wavefront that is behind wins VALU arbitration over one that is ahead, so the wavefronts of a
